@@ -1,0 +1,157 @@
+/*
+ * nyskoop.h -- C-ABI of libnyskoop.so: MI355X (gfx950) Nystrom-Koopman regression hot path.
+ *
+ * The reference (LCSL/nys-koop-lqr) has no FFI: its boundary is the Python class surface of
+ * regressors.py.  Each entry point below names the reference interface it replaces (file:line into
+ * /root/reference).  INTEGRATION.md shows the ctypes stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - All matrices are row-major float64 with an explicit leading dimension (in elements), so strided views
+ *     such as X[:, :d] of an n x (d+p) array are passed without copying (regressors.py:52,142).
+ *   - Every data pointer may be a HOST pointer or a DEVICE (HIP) pointer; the library detects which
+ *     (hipPointerGetAttributes).  Host buffers are staged through HBM by the library; device buffers are used
+ *     in place.  All buffers are caller-owned; the library never retains a caller pointer after return.
+ *   - Return value: NK_OK (0) or a negative NK_ERR_* code; nk_last_error() gives a thread-local message.
+ *     No exceptions or aborts cross the ABI.
+ *   - One nk_ctx per (thread, device).  Calls on distinct contexts are re-entrant; a context is not
+ *     thread-safe.  A context owns one HIP stream and a grow-only HBM workspace.
+ *   - There is NO CPU fallback: without a usable HIP device nk_create fails with NK_ERR_NO_DEVICE.
+ */
+#ifndef NYSKOOP_H
+#define NYSKOOP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NK_ABI_VERSION 1
+
+enum {
+  NK_OK = 0,
+  NK_ERR_BAD_ARG = -1,        /* NULL / negative size / lengthscale-dimension mismatch (sklearn ValueError) */
+  NK_ERR_HIP = -2,            /* a HIP runtime call failed */
+  NK_ERR_NOT_SPD = -3,        /* Cholesky met a non-positive pivot (reference: lstsq would truncate) */
+  NK_ERR_OOM = -4,            /* HBM allocation failed */
+  NK_ERR_NO_CONVERGENCE = -5, /* matrix square-root iteration did not converge */
+  NK_ERR_NO_DEVICE = -6       /* no gfx950 device visible */
+};
+
+/* kernel families: regressors.py:15-22 (RBF, anisotropic), :24-26 (Matern nu=2.5), :28-30 (DotProduct) */
+enum { NK_KERNEL_RBF = 0, NK_KERNEL_MATERN52 = 1, NK_KERNEL_LINEAR = 2 };
+
+typedef struct nk_kernel_desc {
+  int32_t type;              /* NK_KERNEL_* */
+  int32_t d;                 /* state dimension the kernel acts on */
+  int32_t n_lengthscale;     /* 1 (isotropic) or d (anisotropic); ignored for LINEAR */
+  int32_t reserved;
+  const double* lengthscale; /* HOST pointer, n_lengthscale entries */
+  double sigma0;             /* LINEAR only: k(x,y) = x.y + sigma0^2 */
+} nk_kernel_desc;
+
+/* per-fit diagnostics, all times in milliseconds measured with HIP events on the context's stream */
+typedef struct nk_fit_stats {
+  double ms_total;     /* whole nk_nystrom_fit call, device side */
+  double ms_upload;    /* host->HBM staging (0 when inputs are device pointers) */
+  double ms_kmat;      /* kernel-matrix builds K_nm (in, out) and K_mm */
+  double ms_gram;      /* the four Gram contractions */
+  double ms_sqrt;      /* matrix square root of K_mm */
+  double ms_solve;     /* Cholesky factorisations, triangular solves, operator products */
+  double ms_gram_kernel_avg; /* average duration of one launch of the dominant Gram kernel */
+  int32_t gram_kernel_launches;
+  int32_t sqrt_iters;
+  double sqrt_residual;      /* ||Z Y - I||_F / sqrt(m) at exit */
+  double gram_flops;         /* algorithmic flop of the Gram contractions actually issued */
+  double kmat_pairs;         /* number of (row,row,dim) triples evaluated by the kernel-matrix builds */
+} nk_fit_stats;
+
+typedef struct nk_ctx nk_ctx;
+typedef struct nk_model nk_model;
+
+/* ---- library / context ------------------------------------------------------------------------------ */
+int nk_version(void);
+const char* nk_last_error(void);
+int nk_device_count(void);
+int nk_create(int device, nk_ctx** out);
+int nk_destroy(nk_ctx* ctx);
+int nk_synchronize(nk_ctx* ctx);
+/* the hipStream_t all work of this context is launched on (for event timing by the caller) */
+void* nk_stream(nk_ctx* ctx);
+
+/* ---- kernel matrix: replaces `kern.kernel(A, B)` (regressors.py:22,26,30 -> sklearn RBF/Matern/DotProduct
+ *      __call__): out[i][j] = k(A[i,:], B[j,:]),  A: nA x d, B: nB x d, out: nA x nB. ------------------------ */
+int nk_kernel_matrix(nk_ctx* ctx, const nk_kernel_desc* kd,
+                     const double* A, int64_t lda, int64_t nA,
+                     const double* B, int64_t ldb, int64_t nB,
+                     double* out, int64_t ldo);
+
+/* ---- fit: replaces KoopmanNystromRegressor.fit given landmarks (regressors.py:136-169).
+ *   X: n x (d+p) rows [state | input] (the array the reference's fit(X, Y) receives), Y: n x d.
+ *   row_ranges: optional 2*n_ranges int64 [begin,end) pairs selecting the training rows (K-fold training
+ *     sets are two contiguous ranges, benchmark_lqr_cloth.py:52-65); NULL = all n rows.
+ *   Zin / Zout: m x d landmark rows (nystrom_centers_input/_output transposed; regressors.py:129-134);
+ *     Zin may be NULL or equal to Zout (the reference's default, :133-134).
+ *   gamma, jitter: regressors.py:127,120.   The fitted operators live in *model (device resident). ------ */
+int nk_nystrom_fit(nk_ctx* ctx, const nk_kernel_desc* kd,
+                   const double* X, int64_t ldx, const double* Y, int64_t ldy,
+                   int64_t n, int32_t d, int32_t p,
+                   const int64_t* row_ranges, int32_t n_ranges,
+                   const double* Zin, int64_t ldzi, const double* Zout, int64_t ldzo, int32_t m,
+                   double gamma, double jitter,
+                   nk_model** model, nk_fit_stats* stats);
+
+/* rebuild a device model from host copies (un-pickling a regressor, benchmark_lqr_cloth.py:266-267 /
+ * closed_loop_lqr_control.m:158-161); recomputes K_mm^{-1/2} from the landmarks once. A,B,C,W may be NULL. */
+int nk_model_create(nk_ctx* ctx, const nk_kernel_desc* kd, const double* Zout, int64_t ldz,
+                    int32_t m, int32_t d, int32_t p, double jitter,
+                    const double* A, const double* B, const double* C, const double* W,
+                    nk_model** model);
+int nk_model_destroy(nk_model* model);
+
+/* which: 'A' m x m, 'B' m x p, 'C' d x m, 'W' d x (m+p), 'S' m x m (K_mm^{1/2}), 'I' m x m (K_mm^{-1/2}),
+ *        'Z' m x d landmarks.   regressors.py:158-159,166,169. */
+int nk_model_get(nk_ctx* ctx, const nk_model* model, char which, double* out, int64_t ldo);
+int nk_model_dims(const nk_model* model, int32_t* m, int32_t* d, int32_t* p);
+
+/* ---- lift: replaces KoopmanNystromRegressor.lift (regressors.py:171-178) with K_mm^{-1/2} cached.
+ *   Xq: nq x d query rows; out: nq x m (row i = phi(x_i); the reference returns the transpose, m x nq). ---- */
+int nk_lift(nk_ctx* ctx, const nk_model* model, const double* Xq, int64_t ldx, int64_t nq,
+            double* out, int64_t ldo);
+
+/* ---- predict: replaces KoopmanRegressor.predict (regressors.py:48-55). Xaug: nq x (d+p); out: nq x d. -- */
+int nk_predict(nk_ctx* ctx, const nk_model* model, const double* Xaug, int64_t ldx, int64_t nq,
+               double* out, int64_t ldo);
+
+/* ---- CV score: sklearn scorer 'neg_root_mean_squared_error' on a held-out block
+ *      (benchmark_lqr_cloth.py:55): -(mean over columns of sqrt(mean over rows of (Y - predict(X))^2)). ---- */
+int nk_score_neg_rmse(nk_ctx* ctx, const nk_model* model, const double* Xaug, int64_t ldx,
+                      const double* Ytrue, int64_t ldy, int64_t nq, double* score);
+
+/* ---- open-loop rollout: replaces the loop of validate_dyn_sys (benchmark_lqr_cloth.py:23-32) for a batch
+ *   of trajectories.  x0: batch x d initial states; U: batch x T x p controls (row t of trajectory b at
+ *   U + (b*T + t)*p); out_x: batch x T x d with out_x[b][0] = C lift(x0_b), out_x[b][t+1] = C(A z_t + B u_t);
+ *   out_z (optional, may be NULL): batch x T x m lifted states. ------------------------------------------ */
+int nk_rollout(nk_ctx* ctx, const nk_model* model, const double* x0, int64_t ldx0,
+               const double* U, int32_t T, int32_t batch, double* out_x, double* out_z);
+
+/* ---- closed loop in lifted space: replaces the loop of lqr_control (benchmark_lqr_cloth.py:79-84).
+ *   K: p x m gain; phi0, phi_ref: m-vectors; out_x: steps x d visited states C phi_t; out_u: steps x p. ---- */
+int nk_closed_loop(nk_ctx* ctx, const nk_model* model, const double* K, const double* phi0,
+                   const double* phi_ref, int32_t steps, double* out_x, double* out_u);
+
+/* ---- building blocks exported for parity tests and reuse (device or host pointers) --------------------- */
+/* C[M x N] = alpha * op(A) op(B) + beta * C;  transA: A is stored K x M;  transB: B is stored N x K. */
+int nk_gemm(nk_ctx* ctx, int transA, int transB, int64_t M, int64_t N, int64_t K, double alpha,
+            const double* A, int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc);
+/* S = P^{1/2}, Sinv = P^{-1/2} for symmetric positive definite P (m x m); regressors.py:140,163,175. */
+int nk_sqrtm_spd(nk_ctx* ctx, const double* P, int64_t ldp, int32_t m, double* S, double* Sinv,
+                 int32_t* iters, double* residual);
+/* X = P^{-1} R for symmetric positive definite P (m x m), R: m x nrhs; regressors.py:155,165. */
+int nk_solve_spd(nk_ctx* ctx, const double* P, int64_t ldp, int32_t m, const double* R, int64_t ldr,
+                 int32_t nrhs, double* X, int64_t ldxo);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NYSKOOP_H */

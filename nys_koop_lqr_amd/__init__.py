@@ -1,0 +1,13 @@
+"""nys_koop_lqr_amd -- MI355X (gfx950) drop-in for the Nystrom-Koopman fit / lift / predict / rollout surface of
+LCSL/nys-koop-lqr's regressors.py.  Python host classes call hand-written HIP kernels through the C-ABI of
+libnyskoop.so (include/nyskoop.h) with ctypes.  There is no CPU fallback: importing works anywhere, but any
+compute call without the built library and a gfx950 device raises.
+"""
+from .kernels import KernelWrapper, LinearKernelWrapper, ThreeDimensionalKernel  # noqa: F401
+from .regressors import KoopmanNystromRegressor, KoopmanRegressor  # noqa: F401
+from ._lib import NyskoopError, get_context, library_path  # noqa: F401
+
+__all__ = [
+    "KoopmanRegressor", "KoopmanNystromRegressor", "ThreeDimensionalKernel", "KernelWrapper",
+    "LinearKernelWrapper", "NyskoopError", "get_context", "library_path",
+]

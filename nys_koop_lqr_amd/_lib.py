@@ -1,0 +1,173 @@
+"""ctypes binding of libnyskoop.so (include/nyskoop.h).  Fails loudly: no library or no GPU => exception."""
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+NK_KERNEL_RBF, NK_KERNEL_MATERN52, NK_KERNEL_LINEAR = 0, 1, 2
+NK_OK = 0
+_ERR_NAMES = {-1: "NK_ERR_BAD_ARG", -2: "NK_ERR_HIP", -3: "NK_ERR_NOT_SPD", -4: "NK_ERR_OOM",
+              -5: "NK_ERR_NO_CONVERGENCE", -6: "NK_ERR_NO_DEVICE"}
+
+
+class NyskoopError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"{_ERR_NAMES.get(code, code)}: {msg}")
+        self.code = code
+
+
+class KernelDesc(C.Structure):
+    _fields_ = [("type", C.c_int32), ("d", C.c_int32), ("n_lengthscale", C.c_int32), ("reserved", C.c_int32),
+                ("lengthscale", C.POINTER(C.c_double)), ("sigma0", C.c_double)]
+
+
+class FitStats(C.Structure):
+    _fields_ = [("ms_total", C.c_double), ("ms_upload", C.c_double), ("ms_kmat", C.c_double),
+                ("ms_gram", C.c_double), ("ms_sqrt", C.c_double), ("ms_solve", C.c_double),
+                ("ms_gram_kernel_avg", C.c_double), ("gram_kernel_launches", C.c_int32),
+                ("sqrt_iters", C.c_int32), ("sqrt_residual", C.c_double), ("gram_flops", C.c_double),
+                ("kmat_pairs", C.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+_P = C.c_void_p
+_I64 = C.c_int64
+_I32 = C.c_int32
+_D = C.c_double
+
+# name -> (restype, argtypes); every symbol declared in include/nyskoop.h
+SIGNATURES = {
+    "nk_version": (C.c_int, []),
+    "nk_last_error": (C.c_char_p, []),
+    "nk_device_count": (C.c_int, []),
+    "nk_create": (C.c_int, [C.c_int, C.POINTER(_P)]),
+    "nk_destroy": (C.c_int, [_P]),
+    "nk_synchronize": (C.c_int, [_P]),
+    "nk_stream": (_P, [_P]),
+    "nk_kernel_matrix": (C.c_int, [_P, C.POINTER(KernelDesc), _P, _I64, _I64, _P, _I64, _I64, _P, _I64]),
+    "nk_nystrom_fit": (C.c_int, [_P, C.POINTER(KernelDesc), _P, _I64, _P, _I64, _I64, _I32, _I32,
+                                 C.POINTER(_I64), _I32, _P, _I64, _P, _I64, _I32, _D, _D,
+                                 C.POINTER(_P), C.POINTER(FitStats)]),
+    "nk_model_create": (C.c_int, [_P, C.POINTER(KernelDesc), _P, _I64, _I32, _I32, _I32, _D, _P, _P, _P, _P,
+                                  C.POINTER(_P)]),
+    "nk_model_destroy": (C.c_int, [_P]),
+    "nk_model_get": (C.c_int, [_P, _P, C.c_char, _P, _I64]),
+    "nk_model_dims": (C.c_int, [_P, C.POINTER(_I32), C.POINTER(_I32), C.POINTER(_I32)]),
+    "nk_lift": (C.c_int, [_P, _P, _P, _I64, _I64, _P, _I64]),
+    "nk_predict": (C.c_int, [_P, _P, _P, _I64, _I64, _P, _I64]),
+    "nk_score_neg_rmse": (C.c_int, [_P, _P, _P, _I64, _P, _I64, _I64, C.POINTER(_D)]),
+    "nk_rollout": (C.c_int, [_P, _P, _P, _I64, _P, _I32, _I32, _P, _P]),
+    "nk_closed_loop": (C.c_int, [_P, _P, _P, _P, _P, _I32, _P, _P]),
+    "nk_gemm": (C.c_int, [_P, C.c_int, C.c_int, _I64, _I64, _I64, _D, _P, _I64, _P, _I64, _D, _P, _I64]),
+    "nk_sqrtm_spd": (C.c_int, [_P, _P, _I64, _I32, _P, _P, C.POINTER(_I32), C.POINTER(_D)]),
+    "nk_solve_spd": (C.c_int, [_P, _P, _I64, _I32, _P, _I64, _I32, _P, _I64]),
+}
+
+_lib = None
+_lib_lock = threading.Lock()
+
+
+def library_path():
+    return os.environ.get("NYSKOOP_LIB", os.path.join(_HERE, "libnyskoop.so"))
+
+
+def load_library():
+    """dlopen libnyskoop.so and declare every prototype.  Raises if the library has not been built."""
+    global _lib
+    with _lib_lock:
+        if _lib is None:
+            path = library_path()
+            if not os.path.exists(path):
+                raise NyskoopError(-6, f"{path} not found: build it with `python -c 'import __graft_entry__ as g; "
+                                       f"g.build()'` or `make -C nys_koop_lqr_amd/csrc` (there is no CPU fallback)")
+            lib = C.CDLL(path)
+            for name, (res, args) in SIGNATURES.items():
+                fn = getattr(lib, name)
+                fn.restype = res
+                fn.argtypes = args
+            _lib = lib
+    return _lib
+
+
+def check(rc):
+    if rc != NK_OK:
+        raise NyskoopError(rc, load_library().nk_last_error().decode("utf-8", "replace"))
+
+
+class Mat:
+    """A row-major float64 matrix view handed to the C-ABI: host (numpy) or device (anything with
+    data_ptr()/stride()/shape such as a torch.cuda tensor).  Keeps the owner alive for the call."""
+
+    def __init__(self, obj, rows=None, cols=None):
+        if hasattr(obj, "data_ptr") and hasattr(obj, "stride"):  # device tensor (duck-typed torch)
+            if str(getattr(obj, "dtype", "")).split(".")[-1] not in ("float64", "double"):
+                raise TypeError("device tensors must be float64")
+            if obj.dim() != 2 or obj.stride(1) != 1:
+                raise ValueError("device tensors must be 2-D with unit inner stride")
+            self.owner, self.ptr, self.ld = obj, obj.data_ptr(), int(obj.stride(0))
+            self.shape = (int(obj.shape[0]), int(obj.shape[1]))
+        else:
+            a = np.asarray(obj, dtype=np.float64)
+            if a.ndim == 1:
+                a = a.reshape(1, -1)
+            if a.ndim != 2:
+                raise ValueError("expected a 2-D array")
+            if a.shape[1] > 0 and a.shape[0] > 0 and (a.strides[1] != 8 or a.strides[0] % 8 or a.strides[0] < 8 * a.shape[1]):
+                a = np.ascontiguousarray(a)
+            self.owner, self.ptr = a, a.ctypes.data
+            self.ld = a.strides[0] // 8 if a.shape[0] > 1 else max(a.shape[1], 1)
+            self.shape = a.shape
+        if self.shape[0] <= 1:
+            self.ld = max(self.ld, self.shape[1], 1)
+        if rows is not None and self.shape[0] != rows or cols is not None and self.shape[1] != cols:
+            raise ValueError(f"expected a {rows} x {cols} matrix, got {self.shape}")
+
+
+class Context:
+    """One nk_ctx (HIP stream + HBM workspace) on one device.  Not thread-safe; one per process and device."""
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        h = _P()
+        check(self.lib.nk_create(int(device), C.byref(h)))
+        self.handle = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.nk_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        check(self.lib.nk_synchronize(self.handle))
+
+    @property
+    def stream(self):
+        return self.lib.nk_stream(self.handle)
+
+
+_contexts = {}
+
+
+def default_device():
+    return int(os.environ.get("NYSKOOP_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+
+
+def get_context(device=None):
+    device = default_device() if device is None else int(device)
+    key = (os.getpid(), device)
+    ctx = _contexts.get(key)
+    if ctx is None:
+        ctx = _contexts[key] = Context(device)
+    return ctx

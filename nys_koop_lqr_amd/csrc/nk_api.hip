@@ -1,0 +1,803 @@
+// extern "C" entry points of libnyskoop.so (include/nyskoop.h): context, staging of host/device buffers, and the
+// fit / lift / predict / score / rollout pipelines assembled from the device launchers.
+#include "nk_common.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+namespace nk {
+
+static thread_local std::string g_err;
+
+void set_error(const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+}
+
+bool is_device_ptr(const void* p) {
+  if (p == nullptr) return false;
+  hipPointerAttribute_t attr;
+  hipError_t e = hipPointerGetAttributes(&attr, p);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();  // unregistered host memory: clear the sticky error
+    return false;
+  }
+  return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
+}
+
+// ---- arena -----------------------------------------------------------------------------------------------------
+static int arena_new_chunk(nk_ctx* ctx, size_t bytes) {
+  ArenaChunk c;
+  c.cap = bytes;
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&c.base), bytes);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    set_error("HBM workspace allocation of %zu bytes failed: %s", bytes, hipGetErrorString(e));
+    return NK_ERR_OOM;
+  }
+  ctx->arena.chunks.push_back(c);
+  return NK_OK;
+}
+
+int arena_reset(nk_ctx* ctx) {
+  Arena& a = ctx->arena;
+  if (a.chunks.size() > 1) {  // coalesce: steady state is one chunk and no hipMalloc on the hot path
+    NK_HIP(hipStreamSynchronize(ctx->stream));
+    size_t total = 0;
+    for (auto& c : a.chunks) {
+      total += c.cap;
+      (void)hipFree(c.base);
+    }
+    a.chunks.clear();
+    NK_TRY(arena_new_chunk(ctx, total));
+  }
+  for (auto& c : a.chunks) c.off = 0;
+  a.cur = 0;
+  return NK_OK;
+}
+
+ArenaMark arena_mark(nk_ctx* ctx) {
+  Arena& a = ctx->arena;
+  if (a.chunks.empty()) return ArenaMark{0, 0};
+  return ArenaMark{a.cur, a.chunks[a.cur].off};
+}
+
+void arena_release(nk_ctx* ctx, ArenaMark mk) {
+  Arena& a = ctx->arena;
+  if (a.chunks.empty()) return;
+  for (int i = mk.chunk + 1; i < (int)a.chunks.size(); ++i) a.chunks[i].off = 0;
+  a.cur = mk.chunk;
+  a.chunks[a.cur].off = mk.off;
+}
+
+int arena_alloc(nk_ctx* ctx, size_t bytes, void** out) {
+  Arena& a = ctx->arena;
+  bytes = (bytes + 255) & ~(size_t)255;
+  if (bytes == 0) bytes = 256;
+  for (;;) {
+    if (!a.chunks.empty()) {
+      ArenaChunk& c = a.chunks[a.cur];
+      if (c.off + bytes <= c.cap) {
+        *out = c.base + c.off;
+        c.off += bytes;
+        return NK_OK;
+      }
+      if (a.cur + 1 < (int)a.chunks.size()) {
+        ++a.cur;
+        a.chunks[a.cur].off = 0;
+        continue;
+      }
+    }
+    size_t want = bytes;
+    const size_t min_chunk = (size_t)256 << 20;
+    if (want < min_chunk) want = min_chunk;
+    if (!a.chunks.empty() && want < a.chunks.back().cap) want = a.chunks.back().cap;
+    NK_TRY(arena_new_chunk(ctx, want));
+    a.cur = (int)a.chunks.size() - 1;
+  }
+}
+
+// ---- staging ---------------------------------------------------------------------------------------------------
+// Device view of a caller matrix (rows x cols, leading dimension ld). Host data is copied into the arena.
+struct MatIn {
+  const double* ptr = nullptr;
+  int64_t ld = 0;
+  bool staged = false;
+};
+static int stage_in(nk_ctx* ctx, const double* p, int64_t ld, int64_t rows, int64_t cols, MatIn* out) {
+  if (rows <= 0 || cols <= 0) {
+    out->ptr = p;
+    out->ld = ld;
+    return NK_OK;
+  }
+  if (is_device_ptr(p)) {
+    out->ptr = p;
+    out->ld = ld;
+    out->staged = false;
+    return NK_OK;
+  }
+  const int64_t ldd = cols + (cols & 1);
+  double* d = nullptr;
+  NK_TRY(arena_alloc_t(ctx, (size_t)rows * ldd, &d));
+  NK_HIP(hipMemcpy2DAsync(d, (size_t)ldd * 8, p, (size_t)ld * 8, (size_t)cols * 8, (size_t)rows, hipMemcpyHostToDevice,
+                          ctx->stream));
+  out->ptr = d;
+  out->ld = ldd;
+  out->staged = true;
+  return NK_OK;
+}
+struct MatOut {
+  double* dev = nullptr;
+  int64_t ld = 0;
+  double* host = nullptr;
+  int64_t host_ld = 0;
+  int64_t rows = 0, cols = 0;
+};
+static int stage_out(nk_ctx* ctx, double* p, int64_t ld, int64_t rows, int64_t cols, MatOut* out) {
+  out->rows = rows;
+  out->cols = cols;
+  if (is_device_ptr(p)) {
+    out->dev = p;
+    out->ld = ld;
+    out->host = nullptr;
+    return NK_OK;
+  }
+  const int64_t ldd = cols + (cols & 1);
+  NK_TRY(arena_alloc_t(ctx, (size_t)(rows > 0 ? rows : 1) * ldd, &out->dev));
+  out->ld = ldd;
+  out->host = p;
+  out->host_ld = ld;
+  return NK_OK;
+}
+static int finish_out(nk_ctx* ctx, const MatOut& o) {
+  if (o.host && o.rows > 0 && o.cols > 0)
+    NK_HIP(hipMemcpy2DAsync(o.host, (size_t)o.host_ld * 8, o.dev, (size_t)o.ld * 8, (size_t)o.cols * 8, (size_t)o.rows,
+                            hipMemcpyDeviceToHost, ctx->stream));
+  return NK_OK;
+}
+
+static int check_ctx(nk_ctx* ctx) {
+  if (!ctx) {
+    set_error("null context");
+    return NK_ERR_BAD_ARG;
+  }
+  NK_HIP(hipSetDevice(ctx->device));
+  return arena_reset(ctx);
+}
+
+// 1/lengthscale per dimension on the device (ones for the linear kernel)
+static int make_winv(nk_ctx* ctx, const nk_kernel_desc* kd, int d, double* dst_dev) {
+  NK_REQUIRE(kd != nullptr, "null kernel descriptor");
+  NK_REQUIRE(kd->type >= NK_KERNEL_RBF && kd->type <= NK_KERNEL_LINEAR, "unknown kernel type %d", kd->type);
+  NK_REQUIRE(kd->d == d, "kernel descriptor is for %d dimensions, data has %d", kd->d, d);
+  std::vector<double> w((size_t)d, 1.0);
+  if (kd->type != NK_KERNEL_LINEAR) {
+    NK_REQUIRE(kd->lengthscale != nullptr, "kernel lengthscale pointer is null");
+    // sklearn _check_length_scale: an anisotropic kernel must match the data dimension
+    NK_REQUIRE(kd->n_lengthscale == 1 || kd->n_lengthscale == d,
+               "Anisotropic kernel must have the same number of dimensions as data (%d!=%d)", kd->n_lengthscale, d);
+    for (int k = 0; k < d; ++k) {
+      const double l = kd->lengthscale[kd->n_lengthscale == 1 ? 0 : k];
+      NK_REQUIRE(l > 0.0 && std::isfinite(l), "lengthscale[%d] = %g is not positive", k, l);
+      w[k] = 1.0 / l;
+    }
+  }
+  NK_HIP(hipMemcpyAsync(dst_dev, w.data(), sizeof(double) * d, hipMemcpyHostToDevice, ctx->stream));
+  NK_HIP(hipStreamSynchronize(ctx->stream));  // w is a stack vector
+  return NK_OK;
+}
+
+static int model_alloc(nk_ctx* ctx, int m, int d, int p, nk_model** out) {
+  nk_model* mdl = new nk_model();
+  mdl->device = ctx->device;
+  mdl->m = m; mdl->d = d; mdl->p = p;
+  const size_t mp = (size_t)m + p;
+  const size_t total = (size_t)m * mp /*G=[A B]*/ + (size_t)d * m /*C*/ + (size_t)d * mp /*W*/ + 2 * (size_t)m * m +
+                       (size_t)m * d /*Z*/ + (size_t)d /*winv*/ + 64;
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&mdl->buf), total * sizeof(double));
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    delete mdl;
+    set_error("model allocation failed: %s", hipGetErrorString(e));
+    return NK_ERR_OOM;
+  }
+  double* q = mdl->buf;
+  auto take = [&](size_t cnt) { double* r = q; q += (cnt + 1) & ~(size_t)1; return r; };
+  mdl->A = take((size_t)m * mp);
+  mdl->B = mdl->A + m;  // view into G = [A | B], leading dimension m + p
+  mdl->C = take((size_t)d * m);
+  mdl->W = take((size_t)d * mp);
+  mdl->S = take((size_t)m * m);
+  mdl->Sinv = take((size_t)m * m);
+  mdl->Z = take((size_t)m * d);
+  mdl->winv = take((size_t)d);
+  *out = mdl;
+  return NK_OK;
+}
+
+// phi (nq x m, ld ldo) = k(Xq, Z) * Sinv, processed in row chunks
+static int lift_device(nk_ctx* ctx, const nk_model* mdl, const double* Xq, int64_t ldx, int64_t nq, double* out,
+                       int64_t ldo) {
+  const int m = mdl->m;
+  const int64_t chunk = 32768;
+  const ArenaMark mk = arena_mark(ctx);
+  double* Kq = nullptr;
+  NK_TRY(arena_alloc_t(ctx, (size_t)(nq < chunk ? nq : chunk) * m, &Kq));
+  for (int64_t r0 = 0; r0 < nq; r0 += chunk) {
+    const int64_t len = nq - r0 < chunk ? nq - r0 : chunk;
+    NK_TRY(launch_kmat(ctx, mdl->ktype, Xq + r0 * ldx, ldx, len, mdl->Z, mdl->d, m, mdl->d, mdl->winv, mdl->sigma0, Kq,
+                       m));
+    NK_TRY(launch_gemm(ctx, false, false, len, m, m, 1.0, Kq, m, mdl->Sinv, m, 0.0, out + r0 * ldo, ldo));
+  }
+  arena_release(ctx, mk);
+  return NK_OK;
+}
+
+// out (nq x d) = [phi(X) | U] W^T
+static int predict_device(nk_ctx* ctx, const nk_model* mdl, const double* Xaug, int64_t ldx, int64_t nq, double* out,
+                          int64_t ldo) {
+  const int m = mdl->m, d = mdl->d, p = mdl->p;
+  const int64_t chunk = 32768;
+  const ArenaMark mk = arena_mark(ctx);
+  double* phi = nullptr;
+  NK_TRY(arena_alloc_t(ctx, (size_t)(nq < chunk ? nq : chunk) * m, &phi));
+  for (int64_t r0 = 0; r0 < nq; r0 += chunk) {
+    const int64_t len = nq - r0 < chunk ? nq - r0 : chunk;
+    NK_TRY(lift_device(ctx, mdl, Xaug + r0 * ldx, ldx, len, phi, m));
+    NK_TRY(launch_gemm(ctx, false, true, len, d, m, 1.0, phi, m, mdl->W, m + p, 0.0, out + r0 * ldo, ldo));
+    if (p > 0)
+      NK_TRY(launch_gemm(ctx, false, true, len, d, p, 1.0, Xaug + r0 * ldx + d, ldx, mdl->W + m, m + p, 1.0,
+                         out + r0 * ldo, ldo));
+  }
+  arena_release(ctx, mk);
+  return NK_OK;
+}
+
+static float ev_ms(nk_ctx* ctx, int a, int b) {
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, ctx->ev[a], ctx->ev[b]);
+  return ms;
+}
+
+}  // namespace nk
+
+using namespace nk;
+
+extern "C" {
+
+int nk_version(void) { return NK_ABI_VERSION; }
+
+const char* nk_last_error(void) { return g_err.c_str(); }
+
+int nk_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
+
+int nk_create(int device, nk_ctx** out) {
+  NK_REQUIRE(out != nullptr, "nk_create: null output pointer");
+  *out = nullptr;
+  int n = nk_device_count();
+  if (n <= 0) {
+    set_error("no HIP device visible: libnyskoop has no CPU fallback");
+    return NK_ERR_NO_DEVICE;
+  }
+  NK_REQUIRE(device >= 0 && device < n, "nk_create: device %d out of range (0..%d)", device, n - 1);
+  NK_HIP(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  NK_HIP(hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    set_error("device %d is %s; libnyskoop is built for gfx950 (MI355X) only", device, prop.gcnArchName);
+    return NK_ERR_NO_DEVICE;
+  }
+  nk_ctx* ctx = new nk_ctx();
+  ctx->device = device;
+  ctx->num_cu = prop.multiProcessorCount;
+  NK_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+  NK_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->d_info), 256));
+  NK_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->d_scalars), 64 * sizeof(double)));
+  NK_HIP(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_scalars), 64 * sizeof(double)));
+  for (int i = 0; i < 16; ++i) NK_HIP(hipEventCreate(&ctx->ev[i]));
+  *out = ctx;
+  return NK_OK;
+}
+
+int nk_destroy(nk_ctx* ctx) {
+  if (!ctx) return NK_OK;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  for (auto& c : ctx->arena.chunks) (void)hipFree(c.base);
+  (void)hipFree(ctx->d_info);
+  (void)hipFree(ctx->d_scalars);
+  (void)hipHostFree(ctx->h_scalars);
+  for (int i = 0; i < 16; ++i) (void)hipEventDestroy(ctx->ev[i]);
+  (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return NK_OK;
+}
+
+int nk_synchronize(nk_ctx* ctx) {
+  NK_REQUIRE(ctx != nullptr, "null context");
+  NK_HIP(hipStreamSynchronize(ctx->stream));
+  return NK_OK;
+}
+
+void* nk_stream(nk_ctx* ctx) { return ctx ? reinterpret_cast<void*>(ctx->stream) : nullptr; }
+
+int nk_kernel_matrix(nk_ctx* ctx, const nk_kernel_desc* kd, const double* A, int64_t lda, int64_t nA, const double* B,
+                     int64_t ldb, int64_t nB, double* out, int64_t ldo) {
+  NK_TRY(check_ctx(ctx));
+  NK_REQUIRE(kd && A && B && out, "nk_kernel_matrix: null argument");
+  NK_REQUIRE(nA >= 0 && nB >= 0 && kd->d > 0, "nk_kernel_matrix: negative size");
+  NK_REQUIRE(lda >= kd->d && ldb >= kd->d && ldo >= nB, "nk_kernel_matrix: leading dimension too small");
+  if (nA == 0 || nB == 0) return NK_OK;
+  const int d = kd->d;
+  double* winv = nullptr;
+  NK_TRY(arena_alloc_t(ctx, (size_t)d, &winv));
+  NK_TRY(make_winv(ctx, kd, d, winv));
+  MatIn a, b;
+  NK_TRY(stage_in(ctx, A, lda, nA, d, &a));
+  NK_TRY(stage_in(ctx, B, ldb, nB, d, &b));
+  MatOut o;
+  NK_TRY(stage_out(ctx, out, ldo, nA, nB, &o));
+  NK_TRY(launch_kmat(ctx, kd->type, a.ptr, a.ld, nA, b.ptr, b.ld, nB, d, winv, kd->sigma0, o.dev, o.ld));
+  NK_TRY(finish_out(ctx, o));
+  NK_HIP(hipStreamSynchronize(ctx->stream));
+  return NK_OK;
+}
+
+int nk_nystrom_fit(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int64_t ldx, const double* Y, int64_t ldy,
+                   int64_t n, int32_t d, int32_t p, const int64_t* row_ranges, int32_t n_ranges, const double* Zin,
+                   int64_t ldzi, const double* Zout, int64_t ldzo, int32_t m, double gamma, double jitter,
+                   nk_model** model, nk_fit_stats* stats) {
+  NK_TRY(check_ctx(ctx));
+  NK_REQUIRE(kd && X && Y && Zout && model, "nk_nystrom_fit: null argument");
+  NK_REQUIRE(n > 0 && d > 0 && p >= 0 && m > 0, "nk_nystrom_fit: sizes must be positive (n=%lld d=%d p=%d m=%d)",
+             (long long)n, d, p, m);
+  NK_REQUIRE(ldx >= d + p && ldy >= d && ldzo >= d, "nk_nystrom_fit: leading dimension too small");
+  NK_REQUIRE(std::isfinite(gamma) && std::isfinite(jitter), "nk_nystrom_fit: gamma/jitter not finite");
+  *model = nullptr;
+  std::vector<int64_t> rng;
+  if (row_ranges && n_ranges > 0) {
+    for (int i = 0; i < n_ranges; ++i) {
+      const int64_t b = row_ranges[2 * i], e = row_ranges[2 * i + 1];
+      NK_REQUIRE(0 <= b && b <= e && e <= n, "nk_nystrom_fit: row range %d = [%lld,%lld) outside [0,%lld)", i,
+                 (long long)b, (long long)e, (long long)n);
+      if (e > b) { rng.push_back(b); rng.push_back(e); }
+    }
+  } else {
+    rng.push_back(0); rng.push_back(n);
+  }
+  int64_t n_eff = 0;
+  for (size_t i = 0; i < rng.size(); i += 2) n_eff += rng[i + 1] - rng[i];
+  NK_REQUIRE(n_eff > 0, "nk_nystrom_fit: no training rows selected");
+  const bool same_centers = (Zin == nullptr) || (Zin == Zout && ldzi == ldzo);
+  const int mp = m + p;
+  const double gamma_n = gamma * (double)n_eff;  // regressors.py:127
+
+  nk_model* mdl = nullptr;
+  NK_TRY(model_alloc(ctx, m, d, p, &mdl));
+  struct Guard { nk_model* m; ~Guard() { if (m) nk_model_destroy(m); } } guard{mdl};
+  mdl->ktype = kd->type; mdl->sigma0 = kd->sigma0; mdl->jitter = jitter;
+
+  hipEvent_t* ev = ctx->ev;
+  NK_HIP(hipEventRecord(ev[0], ctx->stream));
+  NK_TRY(make_winv(ctx, kd, d, mdl->winv));
+  MatIn x, y, zi, zo;
+  NK_TRY(stage_in(ctx, X, ldx, n, d + p, &x));
+  NK_TRY(stage_in(ctx, Y, ldy, n, d, &y));
+  NK_TRY(stage_in(ctx, Zout, ldzo, m, d, &zo));
+  if (same_centers) zi = zo; else NK_TRY(stage_in(ctx, Zin, ldzi, m, d, &zi));
+  NK_TRY(launch_copy2d(ctx, zo.ptr, zo.ld, mdl->Z, d, m, d));
+  NK_HIP(hipEventRecord(ev[1], ctx->stream));
+
+  // ---- feature matrix F = [K_nm_in | U | (pad) | K_nm_out], sample-major (regressors.py:141-142,147) ------------
+  const int64_t off_out = (mp + 1) & ~1;
+  const int64_t ldf = (off_out + m + 1) & ~(int64_t)1;
+  double* F = nullptr;
+  NK_TRY(arena_alloc_t(ctx, (size_t)n_eff * ldf, &F));
+  int64_t o = 0;
+  for (size_t i = 0; i < rng.size(); i += 2) {
+    const int64_t b = rng[i], len = rng[i + 1] - rng[i];
+    NK_TRY(launch_kmat(ctx, kd->type, x.ptr + b * x.ld, x.ld, len, zi.ptr, zi.ld, m, d, mdl->winv, kd->sigma0,
+                       F + o * ldf, ldf));
+    if (p > 0) NK_TRY(launch_copy2d(ctx, x.ptr + b * x.ld + d, x.ld, F + o * ldf + m, ldf, len, p));
+    NK_TRY(launch_kmat(ctx, kd->type, y.ptr + b * y.ld, y.ld, len, zo.ptr, zo.ld, m, d, mdl->winv, kd->sigma0,
+                       F + o * ldf + off_out, ldf));
+    o += len;
+  }
+  // ---- landmark kernels (regressors.py:139,143,144) -----------------------------------------------------------------
+  double *Kmm = nullptr, *Kj = nullptr, *Kj_in = nullptr, *Kxo = nullptr;
+  NK_TRY(arena_alloc_t(ctx, (size_t)m * m, &Kmm));
+  NK_TRY(arena_alloc_t(ctx, (size_t)m * m, &Kj));
+  NK_TRY(launch_kmat(ctx, kd->type, zo.ptr, zo.ld, m, zo.ptr, zo.ld, m, d, mdl->winv, kd->sigma0, Kmm, m));
+  NK_TRY(launch_copy2d(ctx, Kmm, m, Kj, m, m, m));
+  NK_TRY(launch_add_diag(ctx, Kj, m, m, jitter));
+  if (same_centers) {
+    Kj_in = Kj;
+    Kxo = Kmm;
+  } else {
+    NK_TRY(arena_alloc_t(ctx, (size_t)m * m, &Kj_in));
+    NK_TRY(arena_alloc_t(ctx, (size_t)m * m, &Kxo));
+    NK_TRY(launch_kmat(ctx, kd->type, zi.ptr, zi.ld, m, zi.ptr, zi.ld, m, d, mdl->winv, kd->sigma0, Kj_in, m));
+    NK_TRY(launch_add_diag(ctx, Kj_in, m, m, jitter));
+    NK_TRY(launch_kmat(ctx, kd->type, zi.ptr, zi.ld, m, zo.ptr, zo.ld, m, d, mdl->winv, kd->sigma0, Kxo, m));
+  }
+  NK_HIP(hipEventRecord(ev[2], ctx->stream));
+
+  // ---- Gram contractions over the samples (regressors.py:151,153,162,164) ------------------------------------------
+  double *G1 = nullptr, *G2 = nullptr, *G3 = nullptr, *G4 = nullptr;
+  NK_TRY(arena_alloc_t(ctx, (size_t)mp * mp, &G1));
+  NK_TRY(arena_alloc_t(ctx, (size_t)m * mp, &G2));
+  NK_TRY(arena_alloc_t(ctx, (size_t)m * m, &G3));
+  NK_TRY(arena_alloc_t(ctx, (size_t)d * m, &G4));
+  GemmOpts sym;
+  sym.tri = TRI_UPPER_MIRROR;
+  float ms_g[3] = {0.f, 0.f, 0.f};
+  const bool timed = stats != nullptr;
+  NK_TRY(launch_gemm(ctx, true, false, mp, mp, n_eff, 1.0, F, ldf, F, ldf, 0.0, G1, mp, sym, timed ? &ms_g[0] : nullptr));
+  NK_TRY(launch_gemm(ctx, true, false, m, mp, n_eff, 1.0, F + off_out, ldf, F, ldf, 0.0, G2, mp, GemmOpts(),
+                     timed ? &ms_g[1] : nullptr));
+  NK_TRY(launch_gemm(ctx, true, false, m, m, n_eff, 1.0, F + off_out, ldf, F + off_out, ldf, 0.0, G3, m, sym,
+                     timed ? &ms_g[2] : nullptr));
+  o = 0;
+  for (size_t i = 0; i < rng.size(); i += 2) {
+    const int64_t b = rng[i], len = rng[i + 1] - rng[i];
+    NK_TRY(launch_gemm(ctx, true, false, d, m, len, 1.0, y.ptr + b * y.ld, y.ld, F + o * ldf + off_out, ldf,
+                       i == 0 ? 0.0 : 1.0, G4, m));
+    o += len;
+  }
+  NK_HIP(hipEventRecord(ev[3], ctx->stream));
+
+  // ---- S = K_mm^{1/2}, S^{-1} (regressors.py:140,163) ------------------------------------------------------------------
+  int it = 0;
+  double resid = 0.0;
+  NK_TRY(sqrtm_spd(ctx, Kj, m, m, mdl->S, mdl->Sinv, &it, &resid));
+  NK_HIP(hipEventRecord(ev[4], ctx->stream));
+
+  // ---- [A B] = S^-1 (Phi_out Phi_in^T) inner^-1 blkdiag(K_xo S^-1, I)   (regressors.py:151-159) ------------------------
+  NK_TRY(launch_axpby2d(ctx, gamma_n, Kj_in, m, 1.0, G1, mp, m, m));               // inner = G1 + gamma_n*blkdiag(K, I)
+  if (p > 0) NK_TRY(launch_add_diag(ctx, G1 + (int64_t)m * mp + m, mp, p, gamma_n));
+  double *right = nullptr, *Linv = nullptr, *T2 = nullptr;
+  const int nblk = (mp + CHOL_NB - 1) / CHOL_NB;
+  NK_TRY(arena_alloc_t(ctx, (size_t)mp * mp, &right));
+  NK_TRY(arena_alloc_t(ctx, (size_t)nblk * CHOL_NB * CHOL_NB, &Linv));
+  NK_TRY(arena_alloc_t(ctx, (size_t)m * mp, &T2));
+  NK_TRY(launch_fill(ctx, right, mp, mp, mp, 0.0));
+  NK_TRY(launch_gemm(ctx, false, false, m, m, m, 1.0, Kxo, m, mdl->Sinv, m, 0.0, right, mp));  // K_xo S^-1
+  if (p > 0) NK_TRY(launch_add_diag(ctx, right + (int64_t)m * mp + m, mp, p, 1.0));
+  NK_TRY(cholesky_lower(ctx, G1, mp, mp, Linv));
+  NK_TRY(cholesky_solve(ctx, G1, mp, mp, Linv, right, mp, mp));                                 // sol
+  NK_TRY(launch_gemm(ctx, false, false, m, mp, mp, 1.0, G2, mp, right, mp, 0.0, T2, mp));       // cross * sol
+  NK_TRY(launch_gemm(ctx, false, false, m, mp, m, 1.0, mdl->Sinv, m, T2, mp, 0.0, mdl->A, mp)); // G = S^-1 (.)
+  // ---- C = (Y Phi_out^T) (gamma_n K + Phi_out Phi_out^T)^-1 S   (regressors.py:162-166) ---------------------------------
+  NK_TRY(launch_axpby2d(ctx, gamma_n, Kj, m, 1.0, G3, m, m, m));
+  double* sol_rec = nullptr;
+  NK_TRY(arena_alloc_t(ctx, (size_t)m * m, &sol_rec));
+  NK_TRY(launch_copy2d(ctx, mdl->S, m, sol_rec, m, m, m));
+  NK_TRY(cholesky_lower(ctx, G3, m, m, Linv));
+  NK_TRY(cholesky_solve(ctx, G3, m, m, Linv, sol_rec, m, m));
+  NK_TRY(launch_gemm(ctx, false, false, d, m, m, 1.0, G4, m, sol_rec, m, 0.0, mdl->C, m));
+  NK_TRY(launch_gemm(ctx, false, false, d, mp, m, 1.0, mdl->C, m, mdl->A, mp, 0.0, mdl->W, mp));  // W = C G (:167)
+  NK_HIP(hipEventRecord(ev[5], ctx->stream));
+  NK_HIP(hipStreamSynchronize(ctx->stream));
+  mdl->has_ops = true;
+
+  if (stats) {
+    memset(stats, 0, sizeof(*stats));
+    stats->ms_total = ev_ms(ctx, 0, 5);
+    stats->ms_upload = (x.staged || y.staged) ? ev_ms(ctx, 0, 1) : 0.0;
+    stats->ms_kmat = ev_ms(ctx, 1, 2);
+    stats->ms_gram = ev_ms(ctx, 2, 3);
+    stats->ms_sqrt = ev_ms(ctx, 3, 4);
+    stats->ms_solve = ev_ms(ctx, 4, 5);
+    stats->ms_gram_kernel_avg = (ms_g[0] + ms_g[1] + ms_g[2]) / 3.0;
+    stats->gram_kernel_launches = 3;
+    stats->sqrt_iters = it;
+    stats->sqrt_residual = resid;
+    const double ne = (double)n_eff;
+    const double t128 = 128.0;
+    auto tiles = [&](double v) { return std::ceil(v / t128); };
+    const double tmp_ = tiles(mp), tm_ = tiles(m);
+    // flop actually issued by the three big tile sets (upper-triangular tile sets for the symmetric Grams)
+    stats->gram_flops = 2.0 * ne * t128 * t128 * (tmp_ * (tmp_ + 1) / 2 + tm_ * tmp_ + tm_ * (tm_ + 1) / 2) +
+                        2.0 * ne * (double)d * m;
+    stats->kmat_pairs = 2.0 * ne * m * d + (same_centers ? 1.0 : 3.0) * (double)m * m * d;
+  }
+  guard.m = nullptr;
+  *model = mdl;
+  return NK_OK;
+}
+
+int nk_model_create(nk_ctx* ctx, const nk_kernel_desc* kd, const double* Zout, int64_t ldz, int32_t m, int32_t d,
+                    int32_t p, double jitter, const double* A, const double* B, const double* C, const double* W,
+                    nk_model** model) {
+  NK_TRY(check_ctx(ctx));
+  NK_REQUIRE(kd && Zout && model, "nk_model_create: null argument");
+  NK_REQUIRE(m > 0 && d > 0 && p >= 0 && ldz >= d, "nk_model_create: bad sizes");
+  *model = nullptr;
+  nk_model* mdl = nullptr;
+  NK_TRY(model_alloc(ctx, m, d, p, &mdl));
+  struct Guard { nk_model* m; ~Guard() { if (m) nk_model_destroy(m); } } guard{mdl};
+  mdl->ktype = kd->type; mdl->sigma0 = kd->sigma0; mdl->jitter = jitter;
+  NK_TRY(make_winv(ctx, kd, d, mdl->winv));
+  MatIn z;
+  NK_TRY(stage_in(ctx, Zout, ldz, m, d, &z));
+  NK_TRY(launch_copy2d(ctx, z.ptr, z.ld, mdl->Z, d, m, d));
+  double* Kj = nullptr;
+  NK_TRY(arena_alloc_t(ctx, (size_t)m * m, &Kj));
+  NK_TRY(launch_kmat(ctx, kd->type, mdl->Z, d, m, mdl->Z, d, m, d, mdl->winv, kd->sigma0, Kj, m));
+  NK_TRY(launch_add_diag(ctx, Kj, m, m, jitter));
+  NK_TRY(sqrtm_spd(ctx, Kj, m, m, mdl->S, mdl->Sinv, nullptr, nullptr));
+  const int mp = m + p;
+  if (A && C) {
+    NK_REQUIRE(p == 0 || B != nullptr, "nk_model_create: B missing");
+    MatIn a, b, c, w;
+    NK_TRY(stage_in(ctx, A, m, m, m, &a));
+    NK_TRY(launch_copy2d(ctx, a.ptr, a.ld, mdl->A, mp, m, m));
+    if (p > 0) {
+      NK_TRY(stage_in(ctx, B, p, m, p, &b));
+      NK_TRY(launch_copy2d(ctx, b.ptr, b.ld, mdl->B, mp, m, p));
+    }
+    NK_TRY(stage_in(ctx, C, m, d, m, &c));
+    NK_TRY(launch_copy2d(ctx, c.ptr, c.ld, mdl->C, m, d, m));
+    if (W) {
+      NK_TRY(stage_in(ctx, W, mp, d, mp, &w));
+      NK_TRY(launch_copy2d(ctx, w.ptr, w.ld, mdl->W, mp, d, mp));
+    } else {
+      NK_TRY(launch_gemm(ctx, false, false, d, mp, m, 1.0, mdl->C, m, mdl->A, mp, 0.0, mdl->W, mp));
+    }
+    mdl->has_ops = true;
+  }
+  NK_HIP(hipStreamSynchronize(ctx->stream));
+  guard.m = nullptr;
+  *model = mdl;
+  return NK_OK;
+}
+
+int nk_model_destroy(nk_model* model) {
+  if (!model) return NK_OK;
+  (void)hipSetDevice(model->device);
+  (void)hipFree(model->buf);
+  delete model;
+  return NK_OK;
+}
+
+int nk_model_dims(const nk_model* model, int32_t* m, int32_t* d, int32_t* p) {
+  NK_REQUIRE(model != nullptr, "null model");
+  if (m) *m = model->m;
+  if (d) *d = model->d;
+  if (p) *p = model->p;
+  return NK_OK;
+}
+
+int nk_model_get(nk_ctx* ctx, const nk_model* mdl, char which, double* out, int64_t ldo) {
+  NK_TRY(check_ctx(ctx));
+  NK_REQUIRE(mdl && out, "nk_model_get: null argument");
+  const int m = mdl->m, d = mdl->d, p = mdl->p, mp = m + p;
+  const double* src = nullptr;
+  int64_t lds = 0, rows = 0, cols = 0;
+  switch (which) {
+    case 'A': src = mdl->A; lds = mp; rows = m; cols = m; break;
+    case 'B': src = mdl->B; lds = mp; rows = m; cols = p; break;
+    case 'C': src = mdl->C; lds = m; rows = d; cols = m; break;
+    case 'W': src = mdl->W; lds = mp; rows = d; cols = mp; break;
+    case 'S': src = mdl->S; lds = m; rows = m; cols = m; break;
+    case 'I': src = mdl->Sinv; lds = m; rows = m; cols = m; break;
+    case 'Z': src = mdl->Z; lds = d; rows = m; cols = d; break;
+    default: set_error("nk_model_get: unknown selector '%c'", which); return NK_ERR_BAD_ARG;
+  }
+  if ((which == 'A' || which == 'B' || which == 'C' || which == 'W') && !mdl->has_ops) {
+    set_error("nk_model_get: model holds no fitted operators");
+    return NK_ERR_BAD_ARG;
+  }
+  if (rows == 0 || cols == 0) return NK_OK;
+  NK_REQUIRE(ldo >= cols, "nk_model_get: leading dimension too small");
+  NK_HIP(hipMemcpy2DAsync(out, (size_t)ldo * 8, src, (size_t)lds * 8, (size_t)cols * 8, (size_t)rows,
+                          is_device_ptr(out) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
+  NK_HIP(hipStreamSynchronize(ctx->stream));
+  return NK_OK;
+}
+
+int nk_lift(nk_ctx* ctx, const nk_model* mdl, const double* Xq, int64_t ldx, int64_t nq, double* out, int64_t ldo) {
+  NK_TRY(check_ctx(ctx));
+  NK_REQUIRE(mdl && Xq && out, "nk_lift: null argument");
+  NK_REQUIRE(nq >= 0 && ldx >= mdl->d && ldo >= mdl->m, "nk_lift: bad sizes");
+  if (nq == 0) return NK_OK;
+  MatIn x;
+  NK_TRY(stage_in(ctx, Xq, ldx, nq, mdl->d, &x));
+  MatOut o;
+  NK_TRY(stage_out(ctx, out, ldo, nq, mdl->m, &o));
+  NK_TRY(lift_device(ctx, mdl, x.ptr, x.ld, nq, o.dev, o.ld));
+  NK_TRY(finish_out(ctx, o));
+  NK_HIP(hipStreamSynchronize(ctx->stream));
+  return NK_OK;
+}
+
+int nk_predict(nk_ctx* ctx, const nk_model* mdl, const double* Xaug, int64_t ldx, int64_t nq, double* out,
+               int64_t ldo) {
+  NK_TRY(check_ctx(ctx));
+  NK_REQUIRE(mdl && Xaug && out, "nk_predict: null argument");
+  NK_REQUIRE(mdl->has_ops, "nk_predict: model holds no fitted operators");
+  NK_REQUIRE(nq >= 0 && ldx >= mdl->d + mdl->p && ldo >= mdl->d, "nk_predict: bad sizes");
+  if (nq == 0) return NK_OK;
+  MatIn x;
+  NK_TRY(stage_in(ctx, Xaug, ldx, nq, mdl->d + mdl->p, &x));
+  MatOut o;
+  NK_TRY(stage_out(ctx, out, ldo, nq, mdl->d, &o));
+  NK_TRY(predict_device(ctx, mdl, x.ptr, x.ld, nq, o.dev, o.ld));
+  NK_TRY(finish_out(ctx, o));
+  NK_HIP(hipStreamSynchronize(ctx->stream));
+  return NK_OK;
+}
+
+int nk_score_neg_rmse(nk_ctx* ctx, const nk_model* mdl, const double* Xaug, int64_t ldx, const double* Ytrue,
+                      int64_t ldy, int64_t nq, double* score) {
+  NK_TRY(check_ctx(ctx));
+  NK_REQUIRE(mdl && Xaug && Ytrue && score, "nk_score_neg_rmse: null argument");
+  NK_REQUIRE(mdl->has_ops, "nk_score_neg_rmse: model holds no fitted operators");
+  NK_REQUIRE(nq > 0 && ldx >= mdl->d + mdl->p && ldy >= mdl->d, "nk_score_neg_rmse: bad sizes");
+  const int d = mdl->d;
+  MatIn x, y;
+  NK_TRY(stage_in(ctx, Xaug, ldx, nq, d + mdl->p, &x));
+  NK_TRY(stage_in(ctx, Ytrue, ldy, nq, d, &y));
+  double *P = nullptr, *colsum = nullptr;
+  NK_TRY(arena_alloc_t(ctx, (size_t)nq * d, &P));
+  NK_TRY(arena_alloc_t(ctx, (size_t)d, &colsum));
+  NK_TRY(predict_device(ctx, mdl, x.ptr, x.ld, nq, P, d));
+  NK_TRY(launch_colsum_sqdiff(ctx, P, d, y.ptr, y.ld, nq, d, colsum));
+  std::vector<double> h((size_t)d);
+  NK_HIP(hipMemcpyAsync(h.data(), colsum, sizeof(double) * d, hipMemcpyDeviceToHost, ctx->stream));
+  NK_HIP(hipStreamSynchronize(ctx->stream));
+  double s = 0.0;
+  for (int j = 0; j < d; ++j) s += std::sqrt(h[j] / (double)nq);
+  *score = -s / d;
+  return NK_OK;
+}
+
+int nk_rollout(nk_ctx* ctx, const nk_model* mdl, const double* x0, int64_t ldx0, const double* U, int32_t T,
+               int32_t batch, double* out_x, double* out_z) {
+  NK_TRY(check_ctx(ctx));
+  NK_REQUIRE(mdl && x0 && out_x, "nk_rollout: null argument");
+  NK_REQUIRE(mdl->has_ops, "nk_rollout: model holds no fitted operators");
+  NK_REQUIRE(T >= 1 && batch >= 1 && ldx0 >= mdl->d, "nk_rollout: bad sizes");
+  const int m = mdl->m, d = mdl->d, p = mdl->p, mp = m + p;
+  NK_REQUIRE(p == 0 || T == 1 || U != nullptr, "nk_rollout: controls missing");
+  MatIn x, u;
+  NK_TRY(stage_in(ctx, x0, ldx0, batch, d, &x));
+  if (p > 0 && T > 1) NK_TRY(stage_in(ctx, U, (int64_t)T * p, batch, (int64_t)T * p, &u));
+  MatOut ox, oz;
+  NK_TRY(stage_out(ctx, out_x, d, (int64_t)batch * T, d, &ox));
+  double* Zall = nullptr;  // [batch][T][m]
+  if (out_z) {
+    NK_TRY(stage_out(ctx, out_z, m, (int64_t)batch * T, m, &oz));
+    NK_REQUIRE(oz.ld == m || oz.host != nullptr, "nk_rollout: internal layout");
+  }
+  if (out_z && oz.ld == m) Zall = oz.dev;
+  else NK_TRY(arena_alloc_t(ctx, (size_t)batch * T * m, &Zall));
+  const int64_t ldz = (int64_t)T * m;
+  NK_TRY(lift_device(ctx, mdl, x.ptr, x.ld, batch, Zall, ldz));  // z_0 = phi(x_0) for every trajectory
+  for (int t = 0; t + 1 < T; ++t) {
+    // z_{t+1} = z_t A^T + u_t B^T      (benchmark_lqr_cloth.py:30)
+    NK_TRY(launch_gemm(ctx, false, true, batch, m, m, 1.0, Zall + (int64_t)t * m, ldz, mdl->A, mp, 0.0,
+                       Zall + (int64_t)(t + 1) * m, ldz));
+    if (p > 0)
+      NK_TRY(launch_gemm(ctx, false, true, batch, m, p, 1.0, u.ptr + (int64_t)t * p, u.ld, mdl->B, mp, 1.0,
+                         Zall + (int64_t)(t + 1) * m, ldz));
+  }
+  NK_TRY(launch_gemm(ctx, false, true, (int64_t)batch * T, d, m, 1.0, Zall, m, mdl->C, m, 0.0, ox.dev, ox.ld));
+  if (out_z && Zall != oz.dev) NK_TRY(launch_copy2d(ctx, Zall, m, oz.dev, oz.ld, (int64_t)batch * T, m));
+  NK_TRY(finish_out(ctx, ox));
+  if (out_z) NK_TRY(finish_out(ctx, oz));
+  NK_HIP(hipStreamSynchronize(ctx->stream));
+  return NK_OK;
+}
+
+int nk_closed_loop(nk_ctx* ctx, const nk_model* mdl, const double* K, const double* phi0, const double* phi_ref,
+                   int32_t steps, double* out_x, double* out_u) {
+  NK_TRY(check_ctx(ctx));
+  NK_REQUIRE(mdl && K && phi0 && phi_ref && out_x && out_u, "nk_closed_loop: null argument");
+  NK_REQUIRE(mdl->has_ops && steps >= 1 && mdl->p > 0, "nk_closed_loop: bad model or sizes");
+  const int m = mdl->m, d = mdl->d, p = mdl->p, mp = m + p;
+  MatIn k, f0, fr;
+  NK_TRY(stage_in(ctx, K, m, p, m, &k));
+  NK_TRY(stage_in(ctx, phi0, m, 1, m, &f0));
+  NK_TRY(stage_in(ctx, phi_ref, m, 1, m, &fr));
+  MatOut ox, ou;
+  NK_TRY(stage_out(ctx, out_x, d, steps, d, &ox));
+  NK_TRY(stage_out(ctx, out_u, p, steps, p, &ou));
+  double *Phi = nullptr, *diff = nullptr;
+  NK_TRY(arena_alloc_t(ctx, (size_t)(steps + 1) * m, &Phi));
+  NK_TRY(arena_alloc_t(ctx, (size_t)m, &diff));
+  NK_TRY(launch_copy2d(ctx, f0.ptr, m, Phi, m, 1, m));
+  for (int t = 0; t < steps; ++t) {
+    double* phi = Phi + (int64_t)t * m;
+    double* ut = ou.dev + (int64_t)t * ou.ld;
+    NK_TRY(launch_copy2d(ctx, fr.ptr, m, diff, m, 1, m));
+    NK_TRY(launch_axpby2d(ctx, -1.0, phi, m, 1.0, diff, m, 1, m));                                 // phi_ref - phi
+    NK_TRY(launch_gemm(ctx, false, true, 1, p, m, 1.0, diff, m, k.ptr, k.ld, 0.0, ut, ou.ld));     // u = K (.)
+    NK_TRY(launch_gemm(ctx, false, true, 1, m, m, 1.0, phi, m, mdl->A, mp, 0.0, phi + m, m));      // A phi
+    NK_TRY(launch_gemm(ctx, false, true, 1, m, p, 1.0, ut, ou.ld, mdl->B, mp, 1.0, phi + m, m));   // + B u
+  }
+  NK_TRY(launch_gemm(ctx, false, true, steps, d, m, 1.0, Phi, m, mdl->C, m, 0.0, ox.dev, ox.ld));  // x_t = C phi_t
+  NK_TRY(finish_out(ctx, ox));
+  NK_TRY(finish_out(ctx, ou));
+  NK_HIP(hipStreamSynchronize(ctx->stream));
+  return NK_OK;
+}
+
+int nk_gemm(nk_ctx* ctx, int transA, int transB, int64_t M, int64_t N, int64_t K, double alpha, const double* A,
+            int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc) {
+  NK_TRY(check_ctx(ctx));
+  NK_REQUIRE(A && B && C && M >= 0 && N >= 0 && K >= 0, "nk_gemm: bad argument");
+  if (M == 0 || N == 0) return NK_OK;
+  MatIn a, b;
+  NK_TRY(stage_in(ctx, A, lda, transA ? K : M, transA ? M : K, &a));
+  NK_TRY(stage_in(ctx, B, ldb, transB ? N : K, transB ? K : N, &b));
+  MatOut c;
+  NK_TRY(stage_out(ctx, C, ldc, M, N, &c));
+  if (c.host && beta != 0.0)
+    NK_HIP(hipMemcpy2DAsync(c.dev, (size_t)c.ld * 8, C, (size_t)ldc * 8, (size_t)N * 8, (size_t)M, hipMemcpyHostToDevice,
+                            ctx->stream));
+  NK_TRY(launch_gemm(ctx, transA != 0, transB != 0, M, N, K, alpha, a.ptr, a.ld, b.ptr, b.ld, beta, c.dev, c.ld));
+  NK_TRY(finish_out(ctx, c));
+  NK_HIP(hipStreamSynchronize(ctx->stream));
+  return NK_OK;
+}
+
+int nk_sqrtm_spd(nk_ctx* ctx, const double* P, int64_t ldp, int32_t m, double* S, double* Sinv, int32_t* iters,
+                 double* residual) {
+  NK_TRY(check_ctx(ctx));
+  NK_REQUIRE(P && S && Sinv && m > 0 && ldp >= m, "nk_sqrtm_spd: bad argument");
+  MatIn p;
+  NK_TRY(stage_in(ctx, P, ldp, m, m, &p));
+  double *s = nullptr, *si = nullptr;
+  NK_TRY(arena_alloc_t(ctx, (size_t)m * m, &s));
+  NK_TRY(arena_alloc_t(ctx, (size_t)m * m, &si));
+  int it = 0;
+  double r = 0.0;
+  NK_TRY(sqrtm_spd(ctx, p.ptr, p.ld, m, s, si, &it, &r));
+  if (iters) *iters = it;
+  if (residual) *residual = r;
+  const hipMemcpyKind k1 = is_device_ptr(S) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+  const hipMemcpyKind k2 = is_device_ptr(Sinv) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+  NK_HIP(hipMemcpyAsync(S, s, sizeof(double) * m * m, k1, ctx->stream));
+  NK_HIP(hipMemcpyAsync(Sinv, si, sizeof(double) * m * m, k2, ctx->stream));
+  NK_HIP(hipStreamSynchronize(ctx->stream));
+  return NK_OK;
+}
+
+int nk_solve_spd(nk_ctx* ctx, const double* P, int64_t ldp, int32_t m, const double* R, int64_t ldr, int32_t nrhs,
+                 double* X, int64_t ldxo) {
+  NK_TRY(check_ctx(ctx));
+  NK_REQUIRE(P && R && X && m > 0 && nrhs > 0 && ldp >= m && ldr >= nrhs && ldxo >= nrhs, "nk_solve_spd: bad argument");
+  MatIn p, r;
+  NK_TRY(stage_in(ctx, P, ldp, m, m, &p));
+  NK_TRY(stage_in(ctx, R, ldr, m, nrhs, &r));
+  double *L = nullptr, *Linv = nullptr, *W = nullptr;
+  const int nblk = (m + CHOL_NB - 1) / CHOL_NB;
+  const int64_t ldw = nrhs + (nrhs & 1);
+  NK_TRY(arena_alloc_t(ctx, (size_t)m * m, &L));
+  NK_TRY(arena_alloc_t(ctx, (size_t)nblk * CHOL_NB * CHOL_NB, &Linv));
+  NK_TRY(arena_alloc_t(ctx, (size_t)m * ldw, &W));
+  NK_TRY(launch_copy2d(ctx, p.ptr, p.ld, L, m, m, m));
+  NK_TRY(launch_copy2d(ctx, r.ptr, r.ld, W, ldw, m, nrhs));
+  NK_TRY(cholesky_lower(ctx, L, m, m, Linv));
+  NK_TRY(cholesky_solve(ctx, L, m, m, Linv, W, ldw, nrhs));
+  NK_HIP(hipMemcpy2DAsync(X, (size_t)ldxo * 8, W, (size_t)ldw * 8, (size_t)nrhs * 8, (size_t)m,
+                          is_device_ptr(X) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
+  NK_HIP(hipStreamSynchronize(ctx->stream));
+  return NK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,130 @@
+// Internal declarations shared by the libnyskoop translation units (not part of the C-ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <string>
+#include <vector>
+
+#include "nyskoop.h"
+
+namespace nk {
+
+void set_error(const char* fmt, ...);
+
+#define NK_HIP(call)                                                                         \
+  do {                                                                                       \
+    hipError_t e_ = (call);                                                                  \
+    if (e_ != hipSuccess) {                                                                  \
+      nk::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return e_ == hipErrorOutOfMemory ? NK_ERR_OOM : NK_ERR_HIP;                            \
+    }                                                                                        \
+  } while (0)
+
+#define NK_TRY(call)            \
+  do {                          \
+    int rc_ = (call);           \
+    if (rc_ != NK_OK) return rc_; \
+  } while (0)
+
+#define NK_REQUIRE(cond, ...)     \
+  do {                            \
+    if (!(cond)) {                \
+      nk::set_error(__VA_ARGS__); \
+      return NK_ERR_BAD_ARG;      \
+    }                             \
+  } while (0)
+
+// Grow-only HBM workspace: a list of chunks with bump pointers, reset at the start of every API call (and then
+// coalesced into one chunk, so the steady state performs no hipMalloc).  All work of a context is on one stream,
+// so releasing back to a mark makes the space reusable by later launches in stream order.
+struct ArenaChunk {
+  char* base = nullptr;
+  size_t cap = 0;
+  size_t off = 0;
+};
+struct Arena {
+  std::vector<ArenaChunk> chunks;
+  int cur = 0;
+};
+struct ArenaMark {
+  int chunk;
+  size_t off;
+};
+
+}  // namespace nk
+
+struct nk_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  nk::Arena arena;
+  int* d_info = nullptr;       // device flag for factorisation failures
+  double* d_scalars = nullptr; // small device scratch for reductions (64 doubles)
+  double* h_scalars = nullptr; // pinned host mirror
+  hipEvent_t ev[16];
+  int num_cu = 256;
+};
+
+struct nk_model {
+  int device = 0;
+  int32_t m = 0, d = 0, p = 0;
+  int32_t ktype = 0;
+  double sigma0 = 0.0;
+  double jitter = 0.0;
+  double* buf = nullptr;  // one allocation holding everything below
+  double *A = nullptr, *B = nullptr, *C = nullptr, *W = nullptr, *S = nullptr, *Sinv = nullptr, *Z = nullptr,
+         *winv = nullptr;  // winv: 1/lengthscale per dimension (d entries)
+  bool has_ops = false;
+};
+
+namespace nk {
+
+// ---- workspace -------------------------------------------------------------------------------------------
+int arena_reset(nk_ctx* ctx);
+ArenaMark arena_mark(nk_ctx* ctx);
+void arena_release(nk_ctx* ctx, ArenaMark mk);
+int arena_alloc(nk_ctx* ctx, size_t bytes, void** out);
+template <typename T>
+inline int arena_alloc_t(nk_ctx* ctx, size_t count, T** out) {
+  return arena_alloc(ctx, count * sizeof(T), reinterpret_cast<void**>(out));
+}
+bool is_device_ptr(const void* p);
+
+// ---- device launchers (all asynchronous on ctx->stream; device pointers only) ---------------------------------
+// kernel matrix out[i][j] = k(A[i,:], B[j,:]); winv = 1/lengthscale (d entries, device)
+int launch_kmat(nk_ctx* ctx, int ktype, const double* A, int64_t lda, int64_t nA, const double* B, int64_t ldb,
+                int64_t nB, int d, const double* winv, double sigma0, double* out, int64_t ldo);
+
+enum { TRI_FULL = 0, TRI_UPPER_MIRROR = 1, TRI_LOWER = 2 };
+struct GemmOpts {
+  int tri = TRI_FULL;  // TRI_UPPER_MIRROR: compute tiles with tn >= tm and mirror; TRI_LOWER: tiles tn <= tm only
+  int splitk = 0;      // 0 = choose automatically
+};
+// C = alpha*op(A)*op(B) + beta*C ; transA: A stored KxM ; transB: B stored NxK
+int launch_gemm(nk_ctx* ctx, bool transA, bool transB, int64_t M, int64_t N, int64_t K, double alpha, const double* A,
+                int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc,
+                const GemmOpts& opts = GemmOpts(), float* ms_kernel = nullptr);
+
+// elementwise / reductions
+int launch_add_diag(nk_ctx* ctx, double* A, int64_t lda, int n, double v);
+int launch_copy2d(nk_ctx* ctx, const double* src, int64_t lds, double* dst, int64_t ldd, int64_t rows, int64_t cols);
+int launch_axpby2d(nk_ctx* ctx, double a, const double* X, int64_t ldx, double b, double* Y, int64_t ldy,
+                   int64_t rows, int64_t cols);  // Y = a*X + b*Y
+int launch_scale_add_identity(nk_ctx* ctx, double a, const double* X, int64_t ldx, double c, double* Y, int64_t ldy,
+                              int n);  // Y = a*X + c*I
+int launch_fill(nk_ctx* ctx, double* A, int64_t lda, int64_t rows, int64_t cols, double v);
+int launch_frob_minus_identity(nk_ctx* ctx, const double* M, int64_t ldm, int n, double* d_out);  // sum (M-I)^2
+int launch_max_abs_rowsum(nk_ctx* ctx, const double* M, int64_t ldm, int n, double* d_out);
+int launch_colsum_sqdiff(nk_ctx* ctx, const double* P, int64_t ldp, const double* Y, int64_t ldy, int64_t rows,
+                         int cols, double* d_colsum);  // colsum[j] = sum_i (P[i][j]-Y[i][j])^2
+int launch_recip(nk_ctx* ctx, const double* in, double* out, int n);
+
+// dense SPD machinery built on the GEMM engine
+int sqrtm_spd(nk_ctx* ctx, const double* P, int64_t ldp, int m, double* S, double* Sinv, int* iters, double* resid);
+// in-place lower Cholesky of P (m x m, ld), Linv workspace holds inverted diagonal blocks
+int cholesky_lower(nk_ctx* ctx, double* P, int64_t ldp, int m, double* Linv /* nblk*NB*NB */);
+int cholesky_solve(nk_ctx* ctx, const double* L, int64_t ldl, int m, const double* Linv, double* R, int64_t ldr,
+                   int nrhs);  // R <- (L L^T)^{-1} R in place
+constexpr int CHOL_NB = 64;
+
+}  // namespace nk

@@ -1,0 +1,424 @@
+// Dense symmetric-positive-definite machinery of the O(m^3) stage, built on the fp64 MFMA GEMM engine:
+//   * matrix square root / inverse square root by the coupled Newton-Schulz iteration (GEMM only),
+//     replacing scipy.linalg.sqrtm + solve(assume_a='her') (regressors.py:140,152,153,163,175,177);
+//   * blocked Cholesky + blocked triangular solves replacing scipy.linalg.lstsq on the (numerically full-rank)
+//     regularised normal matrices (regressors.py:155,165).  A non-positive pivot is reported as NK_ERR_NOT_SPD;
+//     there is no silent rank truncation.
+#include "nk_common.h"
+
+#include <cmath>
+
+namespace nk {
+
+// ---------------------------------------------------------------------------------------------------------------
+// elementwise helpers
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void add_diag_kernel(double* A, int64_t lda, int n, double v) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) A[(int64_t)i * lda + i] += v;
+}
+__global__ void copy2d_kernel(const double* __restrict__ src, int64_t lds, double* __restrict__ dst, int64_t ldd,
+                              int64_t rows, int64_t cols) {
+  const int64_t total = rows * cols;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = e / cols, c = e - r * cols;
+    dst[r * ldd + c] = src[r * lds + c];
+  }
+}
+__global__ void axpby2d_kernel(double a, const double* __restrict__ X, int64_t ldx, double b, double* __restrict__ Y,
+                               int64_t ldy, int64_t rows, int64_t cols) {
+  const int64_t total = rows * cols;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = e / cols, c = e - r * cols;
+    const double y = (b == 0.0) ? 0.0 : b * Y[r * ldy + c];
+    Y[r * ldy + c] = a * X[r * ldx + c] + y;
+  }
+}
+__global__ void scale_add_identity_kernel(double a, const double* __restrict__ X, int64_t ldx, double c,
+                                          double* __restrict__ Y, int64_t ldy, int n) {
+  const int64_t total = (int64_t)n * n;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = e / n, col = e - r * n;
+    Y[r * ldy + col] = a * X[r * ldx + col] + (r == col ? c : 0.0);
+  }
+}
+__global__ void fill_kernel(double* A, int64_t lda, int64_t rows, int64_t cols, double v) {
+  const int64_t total = rows * cols;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = e / cols, c = e - r * cols;
+    A[r * lda + c] = v;
+  }
+}
+__global__ void recip_kernel(const double* in, double* out, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = 1.0 / in[i];
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, 64));
+  return v;
+}
+
+// per-block partial sums of (M - I)^2; finished by a second single-block pass (deterministic order)
+__global__ void __launch_bounds__(256) frob_mi_partial_kernel(const double* __restrict__ M, int64_t ldm, int n,
+                                                              double* __restrict__ partial) {
+  __shared__ double sh[4];
+  const int64_t total = (int64_t)n * n;
+  double s = 0.0;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = e / n, c = e - r * n;
+    const double v = M[r * ldm + c] - (r == c ? 1.0 : 0.0);
+    s = fma(v, v, s);
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+__global__ void __launch_bounds__(256) sum_partials_kernel(const double* __restrict__ partial, int count,
+                                                           double* __restrict__ out) {
+  __shared__ double sh[4];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < count; i += blockDim.x) s += partial[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+// one wave per row: |row| sums, then max over rows via a second pass
+__global__ void __launch_bounds__(256) abs_rowsum_kernel(const double* __restrict__ M, int64_t ldm, int n,
+                                                         double* __restrict__ rowsum) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n) return;
+  double s = 0.0;
+  for (int c = threadIdx.x & 63; c < n; c += 64) s += fabs(M[(int64_t)row * ldm + c]);
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) rowsum[row] = s;
+}
+__global__ void __launch_bounds__(256) max_kernel(const double* __restrict__ v, int count, double* __restrict__ out) {
+  __shared__ double sh[4];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < count; i += blockDim.x) s = fmax(s, v[i]);
+  s = wave_max(s);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = fmax(fmax(sh[0], sh[1]), fmax(sh[2], sh[3]));
+}
+
+// Column sums of squared differences (the RMSE scorer): each workgroup reduces a slab of rows for 64 columns with
+// coalesced row reads; wavefront reduction across the 4 waves through LDS; per-slab partials are summed in order.
+__global__ void __launch_bounds__(256) colsum_sqdiff_partial_kernel(const double* __restrict__ P, int64_t ldp,
+                                                                    const double* __restrict__ Y, int64_t ldy,
+                                                                    int64_t rows, int cols, int rows_per_block,
+                                                                    double* __restrict__ partial) {
+  __shared__ double sh[4][64];
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int w = threadIdx.x >> 6;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+  const int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+  double s = 0.0;
+  if (col < cols)
+    for (int64_t r = r0 + w; r < r1; r += 4) {
+      const double v = P[r * ldp + col] - Y[r * ldy + col];
+      s = fma(v, v, s);
+    }
+  sh[w][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (w == 0 && col < cols)
+    partial[(int64_t)blockIdx.y * cols + col] = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+}
+__global__ void colsum_finish_kernel(const double* __restrict__ partial, int nslabs, int cols,
+                                     double* __restrict__ colsum) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= cols) return;
+  double s = 0.0;
+  for (int k = 0; k < nslabs; ++k) s += partial[(int64_t)k * cols + col];
+  colsum[col] = s;
+}
+
+static inline int grid_for(int64_t total, int num_cu) {
+  int64_t b = (total + 255) / 256;
+  const int64_t cap = (int64_t)num_cu * 8;
+  return (int)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+int launch_add_diag(nk_ctx* ctx, double* A, int64_t lda, int n, double v) {
+  if (n <= 0) return NK_OK;
+  hipLaunchKernelGGL(add_diag_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, A, lda, n, v);
+  NK_HIP(hipGetLastError());
+  return NK_OK;
+}
+int launch_copy2d(nk_ctx* ctx, const double* src, int64_t lds, double* dst, int64_t ldd, int64_t rows, int64_t cols) {
+  if (rows <= 0 || cols <= 0) return NK_OK;
+  hipLaunchKernelGGL(copy2d_kernel, dim3(grid_for(rows * cols, ctx->num_cu)), dim3(256), 0, ctx->stream, src, lds, dst,
+                     ldd, rows, cols);
+  NK_HIP(hipGetLastError());
+  return NK_OK;
+}
+int launch_axpby2d(nk_ctx* ctx, double a, const double* X, int64_t ldx, double b, double* Y, int64_t ldy, int64_t rows,
+                   int64_t cols) {
+  if (rows <= 0 || cols <= 0) return NK_OK;
+  hipLaunchKernelGGL(axpby2d_kernel, dim3(grid_for(rows * cols, ctx->num_cu)), dim3(256), 0, ctx->stream, a, X, ldx, b,
+                     Y, ldy, rows, cols);
+  NK_HIP(hipGetLastError());
+  return NK_OK;
+}
+int launch_scale_add_identity(nk_ctx* ctx, double a, const double* X, int64_t ldx, double c, double* Y, int64_t ldy,
+                              int n) {
+  if (n <= 0) return NK_OK;
+  hipLaunchKernelGGL(scale_add_identity_kernel, dim3(grid_for((int64_t)n * n, ctx->num_cu)), dim3(256), 0, ctx->stream,
+                     a, X, ldx, c, Y, ldy, n);
+  NK_HIP(hipGetLastError());
+  return NK_OK;
+}
+int launch_fill(nk_ctx* ctx, double* A, int64_t lda, int64_t rows, int64_t cols, double v) {
+  if (rows <= 0 || cols <= 0) return NK_OK;
+  hipLaunchKernelGGL(fill_kernel, dim3(grid_for(rows * cols, ctx->num_cu)), dim3(256), 0, ctx->stream, A, lda, rows,
+                     cols, v);
+  NK_HIP(hipGetLastError());
+  return NK_OK;
+}
+int launch_recip(nk_ctx* ctx, const double* in, double* out, int n) {
+  hipLaunchKernelGGL(recip_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, in, out, n);
+  NK_HIP(hipGetLastError());
+  return NK_OK;
+}
+int launch_frob_minus_identity(nk_ctx* ctx, const double* M, int64_t ldm, int n, double* d_out) {
+  const ArenaMark mk = arena_mark(ctx);
+  const int blocks = grid_for((int64_t)n * n, ctx->num_cu);
+  double* partial = nullptr;
+  NK_TRY(arena_alloc_t(ctx, (size_t)blocks, &partial));
+  hipLaunchKernelGGL(frob_mi_partial_kernel, dim3(blocks), dim3(256), 0, ctx->stream, M, ldm, n, partial);
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, ctx->stream, partial, blocks, d_out);
+  NK_HIP(hipGetLastError());
+  arena_release(ctx, mk);
+  return NK_OK;
+}
+int launch_max_abs_rowsum(nk_ctx* ctx, const double* M, int64_t ldm, int n, double* d_out) {
+  const ArenaMark mk = arena_mark(ctx);
+  double* rs = nullptr;
+  NK_TRY(arena_alloc_t(ctx, (size_t)n, &rs));
+  hipLaunchKernelGGL(abs_rowsum_kernel, dim3((n + 3) / 4), dim3(256), 0, ctx->stream, M, ldm, n, rs);
+  hipLaunchKernelGGL(max_kernel, dim3(1), dim3(256), 0, ctx->stream, rs, n, d_out);
+  NK_HIP(hipGetLastError());
+  arena_release(ctx, mk);
+  return NK_OK;
+}
+int launch_colsum_sqdiff(nk_ctx* ctx, const double* P, int64_t ldp, const double* Y, int64_t ldy, int64_t rows,
+                         int cols, double* d_colsum) {
+  const ArenaMark mk = arena_mark(ctx);
+  const int rpb = 256;
+  const int nslabs = (int)((rows + rpb - 1) / rpb);
+  double* partial = nullptr;
+  NK_TRY(arena_alloc_t(ctx, (size_t)nslabs * cols, &partial));
+  hipLaunchKernelGGL(colsum_sqdiff_partial_kernel, dim3((cols + 63) / 64, nslabs), dim3(256), 0, ctx->stream, P, ldp, Y,
+                     ldy, rows, cols, rpb, partial);
+  hipLaunchKernelGGL(colsum_finish_kernel, dim3((cols + 255) / 256), dim3(256), 0, ctx->stream, partial, nslabs, cols,
+                     d_colsum);
+  NK_HIP(hipGetLastError());
+  arena_release(ctx, mk);
+  return NK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// matrix square root: coupled Newton-Schulz  Y <- Y T, Z <- T Z, T = (3I - ZY)/2,  Y0 = P/c, Z0 = I
+//   Y -> (P/c)^{1/2}, Z -> (P/c)^{-1/2}.  Only M = ZY is symmetrised (mirrored upper tiles); symmetrising Y and Z as
+//   well was observed to destabilise the iteration, the plain products are stable.
+// ---------------------------------------------------------------------------------------------------------------
+static int read_scalar(nk_ctx* ctx, const double* d_ptr, double* out) {
+  NK_HIP(hipMemcpyAsync(ctx->h_scalars, d_ptr, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  NK_HIP(hipStreamSynchronize(ctx->stream));
+  *out = ctx->h_scalars[0];
+  return NK_OK;
+}
+
+int sqrtm_spd(nk_ctx* ctx, const double* P, int64_t ldp, int m, double* S, double* Sinv, int* iters, double* resid) {
+  const ArenaMark mk = arena_mark(ctx);
+  const size_t mm = (size_t)m * m;
+  double *Y = nullptr, *Z = nullptr, *Yn = nullptr, *Zn = nullptr, *M = nullptr, *T = nullptr;
+  NK_TRY(arena_alloc_t(ctx, mm, &Y));
+  NK_TRY(arena_alloc_t(ctx, mm, &Z));
+  NK_TRY(arena_alloc_t(ctx, mm, &Yn));
+  NK_TRY(arena_alloc_t(ctx, mm, &Zn));
+  NK_TRY(arena_alloc_t(ctx, mm, &M));
+  NK_TRY(arena_alloc_t(ctx, mm, &T));
+  double c = 0.0;
+  NK_TRY(launch_max_abs_rowsum(ctx, P, ldp, m, ctx->d_scalars));
+  NK_TRY(read_scalar(ctx, ctx->d_scalars, &c));
+  if (!(c > 0.0) || !std::isfinite(c)) {
+    set_error("sqrtm: matrix norm is %g", c);
+    arena_release(ctx, mk);
+    return NK_ERR_NOT_SPD;
+  }
+  NK_TRY(launch_axpby2d(ctx, 1.0 / c, P, ldp, 0.0, Y, m, m, m));
+  NK_TRY(launch_fill(ctx, Z, m, m, m, 0.0));
+  NK_TRY(launch_add_diag(ctx, Z, m, m, 1.0));
+  GemmOpts sym;
+  sym.tri = TRI_UPPER_MIRROR;
+  const int maxit = 100;
+  double r = 1e300, r_prev = 1e300;
+  int it = 0;
+  bool ok = false;
+  for (; it < maxit; ++it) {
+    NK_TRY(launch_gemm(ctx, false, false, m, m, m, 1.0, Z, m, Y, m, 0.0, M, m, sym));
+    NK_TRY(launch_frob_minus_identity(ctx, M, m, m, ctx->d_scalars));
+    double r2 = 0.0;
+    NK_TRY(read_scalar(ctx, ctx->d_scalars, &r2));
+    r_prev = r;
+    r = std::sqrt(r2 / m);
+    if (!std::isfinite(r)) break;
+    // quadratic convergence: once the previous residual was below 1e-7 this iterate sits on the rounding floor
+    if (r < 5e-14 || r_prev < 1e-7) {
+      ok = true;
+      break;
+    }
+    NK_TRY(launch_scale_add_identity(ctx, -0.5, M, m, 1.5, T, m, m));
+    NK_TRY(launch_gemm(ctx, false, false, m, m, m, 1.0, Y, m, T, m, 0.0, Yn, m));
+    NK_TRY(launch_gemm(ctx, false, false, m, m, m, 1.0, T, m, Z, m, 0.0, Zn, m));
+    double* t = Y; Y = Yn; Yn = t;
+    t = Z; Z = Zn; Zn = t;
+  }
+  if (iters) *iters = it;
+  if (resid) *resid = r;
+  if (!ok) {
+    set_error("sqrtm: Newton-Schulz did not converge (residual %g after %d iterations)", r, it);
+    arena_release(ctx, mk);
+    return NK_ERR_NO_CONVERGENCE;
+  }
+  const double sc = std::sqrt(c);
+  NK_TRY(launch_axpby2d(ctx, sc, Y, m, 0.0, S, m, m, m));
+  NK_TRY(launch_axpby2d(ctx, 1.0 / sc, Z, m, 0.0, Sinv, m, m, m));
+  arena_release(ctx, mk);
+  return NK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// blocked Cholesky (lower) with inverted diagonal blocks
+// ---------------------------------------------------------------------------------------------------------------
+// One workgroup factorises a NB x NB diagonal block in LDS and inverts the factor.  Blocks shorter than NB are padded
+// with the identity.
+__global__ void __launch_bounds__(256) potrf_diag_kernel(double* __restrict__ A, int64_t lda, int nb,
+                                                         double* __restrict__ Linv, int* __restrict__ info, int blk) {
+  constexpr int NB = CHOL_NB;
+  __shared__ double L[NB][NB + 1];
+  __shared__ double X[NB][NB + 1];
+  const int tid = threadIdx.x;
+  for (int e = tid; e < NB * NB; e += 256) {
+    const int r = e / NB, c = e % NB;
+    double v = (r == c) ? 1.0 : 0.0;
+    if (r < nb && c < nb) v = (c <= r) ? A[(int64_t)r * lda + c] : 0.0;
+    L[r][c] = v;
+  }
+  __syncthreads();
+  for (int k = 0; k < nb; ++k) {
+    if (tid == 0) {
+      double dkk = L[k][k];
+      if (!(dkk > 0.0) || !isfinite(dkk)) {
+        if (atomicCAS(info, 0, blk * NB + k + 1) == 0) {}
+        dkk = 1.0;
+      }
+      L[k][k] = sqrt(dkk);
+    }
+    __syncthreads();
+    const double dk = L[k][k];
+    if (tid > k && tid < nb) L[tid][k] /= dk;
+    __syncthreads();
+    for (int e = tid; e < NB * NB; e += 256) {
+      const int i = e / NB, j = e % NB;
+      if (j > k && i >= j && i < nb) L[i][j] -= L[i][k] * L[j][k];
+    }
+    __syncthreads();
+  }
+  if (tid < NB) {
+    const int c = tid;
+    for (int i = 0; i < c; ++i) X[i][c] = 0.0;
+    for (int i = c; i < NB; ++i) {
+      double s = (i == c) ? 1.0 : 0.0;
+      for (int j = c; j < i; ++j) s -= L[i][j] * X[j][c];
+      X[i][c] = s / L[i][i];
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < NB * NB; e += 256) {
+    const int r = e / NB, c = e % NB;
+    if (r < nb && c <= r) A[(int64_t)r * lda + c] = L[r][c];
+    Linv[e] = X[r][c];
+  }
+}
+
+int cholesky_lower(nk_ctx* ctx, double* P, int64_t ldp, int m, double* Linv) {
+  constexpr int NB = CHOL_NB;
+  NK_HIP(hipMemsetAsync(ctx->d_info, 0, sizeof(int), ctx->stream));
+  const int nblk = (m + NB - 1) / NB;
+  GemmOpts lower;
+  lower.tri = TRI_LOWER;
+  lower.splitk = 1;
+  GemmOpts one;
+  one.splitk = 1;
+  for (int jb = 0; jb < nblk; ++jb) {
+    const int j0 = jb * NB;
+    const int nbj = m - j0 < NB ? m - j0 : NB;
+    double* Ajj = P + (int64_t)j0 * ldp + j0;
+    double* Li = Linv + (size_t)jb * NB * NB;
+    hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(256), 0, ctx->stream, Ajj, ldp, nbj, Li, ctx->d_info, jb);
+    NK_HIP(hipGetLastError());
+    const int rem = m - j0 - nbj;
+    if (rem > 0) {
+      double* panel = P + (int64_t)(j0 + nbj) * ldp + j0;
+      // panel <- panel * Linv_jj^T   (in place: one n-tile, every workgroup reads exactly the rows it writes)
+      NK_TRY(launch_gemm(ctx, false, true, rem, nbj, nbj, 1.0, panel, ldp, Li, NB, 0.0, panel, ldp, one));
+      // trailing <- trailing - panel * panel^T  (lower tiles)
+      double* trail = P + (int64_t)(j0 + nbj) * ldp + (j0 + nbj);
+      NK_TRY(launch_gemm(ctx, false, true, rem, rem, nbj, -1.0, panel, ldp, panel, ldp, 1.0, trail, ldp, lower));
+    }
+  }
+  int info = 0;
+  NK_HIP(hipMemcpyAsync(ctx->h_scalars, ctx->d_info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  NK_HIP(hipStreamSynchronize(ctx->stream));
+  info = *reinterpret_cast<int*>(ctx->h_scalars);
+  if (info != 0) {
+    set_error("Cholesky: non-positive pivot at index %d of %d (matrix is numerically rank deficient; the reference's "
+              "lstsq would truncate here)", info - 1, m);
+    return NK_ERR_NOT_SPD;
+  }
+  return NK_OK;
+}
+
+int cholesky_solve(nk_ctx* ctx, const double* L, int64_t ldl, int m, const double* Linv, double* R, int64_t ldr,
+                   int nrhs) {
+  constexpr int NB = CHOL_NB;
+  const int nblk = (m + NB - 1) / NB;
+  GemmOpts one;
+  one.splitk = 1;
+  // forward: L T = R
+  for (int jb = 0; jb < nblk; ++jb) {
+    const int j0 = jb * NB;
+    const int nbj = m - j0 < NB ? m - j0 : NB;
+    const double* Li = Linv + (size_t)jb * NB * NB;
+    double* Rj = R + (int64_t)j0 * ldr;
+    NK_TRY(launch_gemm(ctx, false, false, nbj, nrhs, nbj, 1.0, Li, NB, Rj, ldr, 0.0, Rj, ldr, one));
+    const int rem = m - j0 - nbj;
+    if (rem > 0)
+      NK_TRY(launch_gemm(ctx, false, false, rem, nrhs, nbj, -1.0, L + (int64_t)(j0 + nbj) * ldl + j0, ldl, Rj, ldr,
+                         1.0, R + (int64_t)(j0 + nbj) * ldr, ldr, one));
+  }
+  // backward: L^T X = T
+  for (int jb = nblk - 1; jb >= 0; --jb) {
+    const int j0 = jb * NB;
+    const int nbj = m - j0 < NB ? m - j0 : NB;
+    const double* Li = Linv + (size_t)jb * NB * NB;
+    double* Rj = R + (int64_t)j0 * ldr;
+    NK_TRY(launch_gemm(ctx, true, false, nbj, nrhs, nbj, 1.0, Li, NB, Rj, ldr, 0.0, Rj, ldr, one));
+    if (j0 > 0)
+      NK_TRY(launch_gemm(ctx, true, false, j0, nrhs, nbj, -1.0, L + (int64_t)j0 * ldl, ldl, Rj, ldr, 1.0, R, ldr, one));
+  }
+  return NK_OK;
+}
+
+}  // namespace nk

@@ -1,0 +1,278 @@
+"""Host-side mirror of the reference's estimator surface (regressors.py:32-55, 114-178): same constructor, same
+public attributes, same fit / lift / predict shapes and error behaviour, so that the reference's drivers
+(GridSearchCV, validate_dyn_sys, lqr_control, pickling) run unchanged -- with the arithmetic done by the HIP
+kernels of libnyskoop.so through ctypes.  The DARE (control.dlqr in the reference) stays on the host.
+"""
+import ctypes as C
+
+import numpy as np
+from sklearn.base import BaseEstimator
+
+from . import _lib
+from .lqr import dlqr
+
+
+def _is_device_tensor(x):
+    return hasattr(x, "data_ptr") and hasattr(x, "stride")
+
+
+class KoopmanRegressor(BaseEstimator):
+    """regressors.py:32-55."""
+
+    def __init__(self, n_inputs, gamma, m=None):
+        self.gamma = gamma
+        self.m = m
+        self.A = None
+        self.B = None
+        self.C = None
+        self.weights = None
+        self.n_inputs = n_inputs
+
+    def lift(self, X):
+        raise NotImplementedError
+
+    def fit(self, X, Y):
+        raise NotImplementedError
+
+    def predict(self, X_aug):
+        """regressors.py:48-55 for a subclass that only provides `lift` and `weights`: the product W [phi; u] runs
+        on the device through nk_gemm."""
+        n_states = X_aug.shape[1] - self.n_inputs
+        X = np.asarray(X_aug).T
+        phi_X = np.ascontiguousarray(np.vstack((self.lift(X[:n_states, :]), X[n_states:, :])))
+        W = np.ascontiguousarray(self.weights, dtype=np.float64)
+        ctx = _lib.get_context()
+        out = np.empty((W.shape[0], phi_X.shape[1]))
+        _lib.check(ctx.lib.nk_gemm(ctx.handle, 0, 0, W.shape[0], phi_X.shape[1], W.shape[1], 1.0, W.ctypes.data,
+                                   W.shape[1], phi_X.ctypes.data, phi_X.shape[1], 0.0, out.ctypes.data, out.shape[1]))
+        return out.T
+
+
+class KoopmanNystromRegressor(KoopmanRegressor):
+    """regressors.py:114-178, MI355X-native.
+
+    Differences a caller can observe (all additive): `lift`/`predict` reuse K_mm^{-1/2} computed at fit time instead
+    of re-running sqrtm per call (regressors.py:174-175); `fit` accepts `row_ranges` (training rows of a K-fold split
+    without copying) and device-resident inputs; `rollout`, `score_neg_rmse`, `closed_loop` and `solve_lqr` expose
+    the callers' inner loops (benchmark_lqr_cloth.py:18-36, 52-57, 69-104, 238-263) as single calls.
+    """
+
+    def __init__(self, n_inputs, kernel=None, gamma=None, m=None):
+        super().__init__(n_inputs, gamma, m)
+        self.kernel = kernel
+        self.nystrom_centers_input = None
+        self.nystrom_centers_output = None
+        self.jitter = 1e-6
+        self._model = None
+        self._model_key = None
+        self._stats = None
+
+    # ------------------------------------------------------------------------------------------------ plumbing
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state["_model"] = None  # device handles never travel (benchmark_lqr_cloth.py:266-267 pickles regressors)
+        state["_model_key"] = None
+        return state
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+        self.__dict__.setdefault("_model", None)
+        self.__dict__.setdefault("_model_key", None)
+        self.__dict__.setdefault("_stats", None)
+
+    def __del__(self):
+        try:
+            self._drop_model()
+        except Exception:
+            pass
+
+    def _drop_model(self):
+        if getattr(self, "_model", None):
+            _lib.load_library().nk_model_destroy(self._model)
+            self._model = None
+            self._model_key = None
+
+    def _ensure_model(self):
+        """Device model for lift/predict/rollout; rebuilt from host copies after un-pickling or when a caller
+        replaced the landmarks / operators by hand."""
+        if self.nystrom_centers_output is None:
+            raise RuntimeError("regressor has no landmarks: call fit first")
+        key = (id(self.nystrom_centers_output), id(self.A), id(self.B), id(self.C), id(self.weights))
+        if self._model is not None and self._model_key == key:
+            return self._model
+        self._drop_model()
+        ctx = _lib.get_context()
+        Z = np.ascontiguousarray(np.asarray(self.nystrom_centers_output, dtype=np.float64).T)  # m x d
+        m, d = Z.shape
+        kd, keep = self.kernel.kernel.desc(d)
+        p = int(self.n_inputs)
+
+        def ptr(a, shape):
+            if a is None:
+                return None, None
+            a = np.ascontiguousarray(a, dtype=np.float64)
+            if a.shape != shape:
+                raise ValueError(f"operator has shape {a.shape}, expected {shape}")
+            return a.ctypes.data, a
+
+        pa, ka = ptr(self.A, (m, m))
+        pb, kb = ptr(self.B, (m, p))
+        pc, kc = ptr(self.C, (d, m))
+        pw, kw = ptr(self.weights, (d, m + p))
+        h = C.c_void_p()
+        rc = ctx.lib.nk_model_create(ctx.handle, C.byref(kd), Z.ctypes.data, d, m, d, p, float(self.jitter),
+                                     pa, pb, pc, pw, C.byref(h))
+        if rc == -1:
+            raise ValueError(ctx.lib.nk_last_error().decode())
+        _lib.check(rc)
+        self._model, self._model_key = h, key
+        return h
+
+    # ------------------------------------------------------------------------------------------------ fit
+    def fit(self, X, Y, row_ranges=None):
+        """regressors.py:122-169.  X: n x (d+p) rows [state | input], Y: n x d (NumPy arrays, or float64 device
+        tensors already resident in HBM).  Returns None, like the reference."""
+        ctx = _lib.get_context()
+        Xm, Ym = _lib.Mat(X), _lib.Mat(Y)
+        n, d = Ym.shape
+        p = int(self.n_inputs)
+        if Xm.shape != (n, d + p):
+            raise ValueError(f"X has shape {Xm.shape}, expected {(n, d + p)}")
+        if self.nystrom_centers_output is None:  # regressors.py:129-132: global legacy NumPy RNG, n = #samples
+            idx = np.random.choice(np.arange(0, n), size=self.m, replace=False)
+            if _is_device_tensor(Y):
+                rows = Y[idx.tolist()]
+                self.nystrom_centers_output = np.ascontiguousarray(rows.cpu().numpy().T)
+            else:
+                self.nystrom_centers_output = np.asarray(Y).T[:, idx]
+        if self.nystrom_centers_input is None:  # regressors.py:133-134
+            self.nystrom_centers_input = self.nystrom_centers_output
+        Zo = np.ascontiguousarray(np.asarray(self.nystrom_centers_output, dtype=np.float64).T)
+        m = Zo.shape[0]
+        if Zo.shape[1] != d:
+            raise ValueError(f"landmarks have dimension {Zo.shape[1]}, data has {d}")
+        same = self.nystrom_centers_input is self.nystrom_centers_output
+        Zi = Zo if same else np.ascontiguousarray(np.asarray(self.nystrom_centers_input, dtype=np.float64).T)
+        kd, keep = self.kernel.kernel.desc(d)
+        rr, n_rr = None, 0
+        if row_ranges is not None:
+            flat = np.ascontiguousarray(np.asarray(row_ranges, dtype=np.int64).reshape(-1))
+            rr, n_rr = flat.ctypes.data_as(C.POINTER(C.c_int64)), flat.size // 2
+        stats = _lib.FitStats()
+        h = C.c_void_p()
+        self._drop_model()
+        rc = ctx.lib.nk_nystrom_fit(ctx.handle, C.byref(kd), Xm.ptr, Xm.ld, Ym.ptr, Ym.ld, n, d, p, rr, n_rr,
+                                    None if same else Zi.ctypes.data, d, Zo.ctypes.data, d, m,
+                                    float(self.gamma), float(self.jitter), C.byref(h), C.byref(stats))
+        if rc == -1:
+            raise ValueError(ctx.lib.nk_last_error().decode())
+        if rc == -3:
+            raise np.linalg.LinAlgError(ctx.lib.nk_last_error().decode())
+        _lib.check(rc)
+        self._model = h
+        self._stats = stats.as_dict()
+        G = np.empty((m, m + p))
+        self.C = np.empty((d, m))
+        self.weights = np.empty((d, m + p))
+        A = np.empty((m, m))
+        B = np.empty((m, p))
+        for which, arr in (("A", A), ("B", B), ("C", self.C), ("W", self.weights)):
+            if arr.size:
+                _lib.check(ctx.lib.nk_model_get(ctx.handle, h, which.encode(), arr.ctypes.data, arr.shape[1]))
+        G[:, :m], G[:, m:] = A, B
+        self.A = G[:, :m]  # views of G_ls, as in regressors.py:158-159
+        self.B = G[:, m:]
+        self._model_key = (id(self.nystrom_centers_output), id(self.A), id(self.B), id(self.C), id(self.weights))
+
+    # ------------------------------------------------------------------------------------------------ lift / predict
+    def lift(self, X):
+        """regressors.py:171-178: X is d x n_q (not augmented); returns phi, m x n_q."""
+        ctx = _lib.get_context()
+        h = self._ensure_model()
+        Xq = _lib.Mat(X.t() if _is_device_tensor(X) else np.asarray(X, dtype=np.float64).T)
+        nq = Xq.shape[0]
+        m = np.asarray(self.nystrom_centers_output).shape[1]
+        out = np.empty((nq, m))
+        _lib.check(ctx.lib.nk_lift(ctx.handle, h, Xq.ptr, Xq.ld, nq, out.ctypes.data, m))
+        return out.T
+
+    def predict(self, X_aug):
+        """regressors.py:48-55: X_aug is n_q x (d+p); returns n_q x d."""
+        ctx = _lib.get_context()
+        h = self._ensure_model()
+        Xm = _lib.Mat(X_aug)
+        d = np.asarray(self.nystrom_centers_output).shape[0]
+        if Xm.shape[1] != d + int(self.n_inputs):
+            raise ValueError(f"X_aug has {Xm.shape[1]} columns, expected {d + int(self.n_inputs)}")
+        out = np.empty((Xm.shape[0], d))
+        _lib.check(ctx.lib.nk_predict(ctx.handle, h, Xm.ptr, Xm.ld, Xm.shape[0], out.ctypes.data, d))
+        return out
+
+    def score_neg_rmse(self, X_aug, Y):
+        """sklearn's 'neg_root_mean_squared_error' of predict(X_aug) against Y, reduced on the device
+        (benchmark_lqr_cloth.py:55)."""
+        ctx = _lib.get_context()
+        h = self._ensure_model()
+        Xm, Ym = _lib.Mat(X_aug), _lib.Mat(Y)
+        s = C.c_double()
+        _lib.check(ctx.lib.nk_score_neg_rmse(ctx.handle, h, Xm.ptr, Xm.ld, Ym.ptr, Ym.ld, Xm.shape[0], C.byref(s)))
+        return s.value
+
+    # ------------------------------------------------------------------------------------------------ callers' loops
+    def rollout(self, x0, controls, return_lifted=False):
+        """Open-loop forecast of validate_dyn_sys (benchmark_lqr_cloth.py:23-32).
+
+        x0: (d,) / (d,1) with controls (p, T)  -> simulated (d, T) [and lifted (m, T)];
+        x0: (batch, d) with controls (batch, T, p) -> (batch, T, d) [and (batch, T, m)]."""
+        ctx = _lib.get_context()
+        h = self._ensure_model()
+        d, m = np.asarray(self.nystrom_centers_output).shape
+        p = int(self.n_inputs)
+        controls = np.asarray(controls, dtype=np.float64)
+        single = controls.ndim == 2
+        if single:
+            x0b = np.ascontiguousarray(np.asarray(x0, dtype=np.float64).reshape(1, d))
+            U = np.ascontiguousarray(controls.T).reshape(1, controls.shape[1], p)
+        else:
+            x0b = np.ascontiguousarray(np.asarray(x0, dtype=np.float64).reshape(-1, d))
+            U = np.ascontiguousarray(controls)
+        batch, T = U.shape[0], U.shape[1]
+        out_x = np.empty((batch, T, d))
+        out_z = np.empty((batch, T, m)) if return_lifted else None
+        _lib.check(ctx.lib.nk_rollout(ctx.handle, h, x0b.ctypes.data, d, U.ctypes.data, T, batch, out_x.ctypes.data,
+                                      None if out_z is None else out_z.ctypes.data))
+        if single:
+            return (out_x[0].T, out_z[0].T) if return_lifted else out_x[0].T
+        return (out_x, out_z) if return_lifted else out_x
+
+    def closed_loop(self, K, phi0, phi_ref, num_steps):
+        """Lifted closed loop of lqr_control (benchmark_lqr_cloth.py:79-84): returns (visited (d, steps),
+        u_ops (p, steps))."""
+        ctx = _lib.get_context()
+        h = self._ensure_model()
+        d, m = np.asarray(self.nystrom_centers_output).shape
+        p = int(self.n_inputs)
+        K = np.ascontiguousarray(K, dtype=np.float64)
+        f0 = np.ascontiguousarray(np.asarray(phi0, dtype=np.float64).reshape(m))
+        fr = np.ascontiguousarray(np.asarray(phi_ref, dtype=np.float64).reshape(m))
+        if K.shape != (p, m):
+            raise ValueError(f"gain has shape {K.shape}, expected {(p, m)}")
+        ox, ou = np.empty((num_steps, d)), np.empty((num_steps, p))
+        _lib.check(ctx.lib.nk_closed_loop(ctx.handle, h, K.ctypes.data, f0.ctypes.data, fr.ctypes.data, int(num_steps),
+                                          ox.ctypes.data, ou.ctypes.data))
+        return ox.T, ou.T
+
+    def solve_lqr(self, Q=None, R=None, c=0.0075):
+        """Host DARE, standing in for control.dlqr(A, B, Q, R) (benchmark_lqr_cloth.py:238-240,262): by default
+        Q = c * C^T C symmetrised and R = I.  Returns the gain K (p x m)."""
+        if Q is None:
+            Q = c * self.C.T @ self.C
+            Q = (Q + Q.T) / 2
+        if R is None:
+            R = np.eye(int(self.n_inputs))
+        K, _ = dlqr(self.A, self.B, Q, R)
+        return K
+
+    @property
+    def fit_stats_(self):
+        return self._stats

@@ -1,0 +1,267 @@
+"""GPU parity tests proper: the HIP path (through the C-ABI, ctypes) against the CPU oracle on the same seeded
+inputs and against the committed golden vectors produced by the reference.  Run with `-m gpu` on an MI355X."""
+import ctypes as C
+import pickle
+
+import numpy as np
+import pytest
+
+from conftest import relf
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def nk():
+    import nys_koop_lqr_amd as nk
+    nk.get_context()  # fails loudly without a gfx950 device / built library
+    return nk
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import nk_oracle
+    return nk_oracle
+
+
+def _kernels(nk, O, name, ls, d):
+    if "matern" in name:
+        return nk.KernelWrapper(ls), O.KernelWrapper(ls)
+    l3 = ls if ls.size == 3 else np.repeat(ls, 3)
+    return nk.ThreeDimensionalKernel(*l3, d), O.ThreeDimensionalKernel(*l3, d)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# a1/a2/a3: kernel matrices
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("nA,nB,d", [(1, 1, 1), (5, 3, 2), (130, 129, 3), (257, 64, 17), (300, 200, 192), (64, 500, 384),
+                                     (1000, 37, 1)])
+@pytest.mark.parametrize("family", ["rbf", "matern", "linear"])
+def test_kernel_matrix_vs_oracle(nk, O, nA, nB, d, family):
+    rng = np.random.default_rng(nA * 1000 + nB + d)
+    A = rng.standard_normal((nA, d))
+    B = rng.standard_normal((nB, d))
+    ls = rng.uniform(0.5, 3.0, size=d) * np.sqrt(d)
+    if family == "rbf":
+        got = nk.kernels.DeviceKernel(0, ls)(A, B)
+        ref = O.rbf_kernel(A, B, ls)
+    elif family == "matern":
+        got = nk.kernels.DeviceKernel(1, ls)(A, B)
+        ref = O.matern52_kernel(A, B, ls)
+    else:
+        got = nk.LinearKernelWrapper(0.7).kernel(A, B)
+        ref = O.linear_kernel(A, B, 0.7)
+    assert got.shape == ref.shape
+    err = np.max(np.abs(got - ref) / np.maximum(np.abs(ref), 1e-300))
+    assert err < (1e-12 if family == "linear" else 2e-13), err
+
+
+def test_kernel_matrix_golden_and_properties(nk, golden):
+    g = golden("f4b_kernels.npz")
+    A, B = g["A"], g["B"]
+    assert np.max(np.abs(nk.LinearKernelWrapper(0.7).kernel(A, B) - g["linear"])) < 1e-13
+    assert np.max(np.abs(nk.KernelWrapper(np.linspace(0.5, 2.0, 7)).kernel(A, B) - g["matern"])) < 1e-14
+    assert np.max(np.abs(nk.ThreeDimensionalKernel(0.5, 1.5, 3.0, 7).kernel(A, B) - g["rbf3d"])) < 1e-14
+    Ks = nk.ThreeDimensionalKernel(0.5, 1.5, 3.0, 7).kernel(A, A)
+    assert np.all(np.diag(Ks) == 1.0) and np.array_equal(Ks, Ks.T)  # direct differences: exact, bitwise symmetric
+    # strided views (X[:, :d] of an n x (d+p) array) go through without copies
+    big = np.random.default_rng(0).standard_normal((50, 9))
+    assert np.allclose(nk.KernelWrapper([1.0] * 7).kernel(big[:, :7], B), nk.KernelWrapper([1.0] * 7).kernel(big[:, :7].copy(), B), rtol=0, atol=0)
+    with pytest.raises(ValueError):  # sklearn _check_length_scale
+        nk.KernelWrapper([1.0, 2.0, 3.0]).kernel(A, B)
+    assert nk.KernelWrapper([1.0] * 7).kernel(A[:0], B).shape == (0, 13)  # empty input
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# building blocks
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K", [(1, 1, 1), (7, 5, 3), (128, 128, 16), (129, 127, 33), (200, 6, 1000), (64, 300, 4097),
+                                   (513, 259, 130)])
+@pytest.mark.parametrize("tA,tB", [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_gemm_vs_numpy(nk, M, N, K, tA, tB):
+    from nys_koop_lqr_amd import _lib
+    ctx = nk.get_context()
+    rng = np.random.default_rng(M + 10 * N + 100 * K + tA + 2 * tB)
+    A = rng.standard_normal((K, M) if tA else (M, K))
+    B = rng.standard_normal((N, K) if tB else (K, N))
+    Cm = rng.standard_normal((M, N))
+    ref = 0.5 * (A.T if tA else A) @ (B.T if tB else B) - 1.5 * Cm
+    out = Cm.copy()
+    _lib.check(ctx.lib.nk_gemm(ctx.handle, tA, tB, M, N, K, 0.5, A.ctypes.data, A.shape[1], B.ctypes.data, B.shape[1],
+                               -1.5, out.ctypes.data, N))
+    scale = np.abs(A.T if tA else A) @ np.abs(B.T if tB else B) + 1.5 * np.abs(Cm)
+    assert np.max(np.abs(out - ref) / scale) < 1e-14
+
+
+def test_gemm_asymmetric_identity(nk):
+    """A = I against an ASYMMETRIC B: catches a transposed C write / wrong MFMA f64 fragment map."""
+    from nys_koop_lqr_amd import _lib
+    ctx = nk.get_context()
+    n = 192
+    B = np.arange(n * n, dtype=np.float64).reshape(n, n)
+    out = np.zeros((n, n))
+    I = np.eye(n)
+    _lib.check(ctx.lib.nk_gemm(ctx.handle, 0, 0, n, n, n, 1.0, I.ctypes.data, n, B.ctypes.data, n, 0.0, out.ctypes.data, n))
+    assert np.array_equal(out, B)
+
+
+@pytest.mark.parametrize("m", [5, 64, 100, 333])
+def test_sqrtm_and_solve_spd(nk, m):
+    from nys_koop_lqr_amd import _lib
+    import scipy.linalg
+    ctx = nk.get_context()
+    rng = np.random.default_rng(m)
+    Q = rng.standard_normal((m, 3 * m))
+    P = Q @ Q.T / (3 * m) + 1e-3 * np.eye(m)
+    S, Si = np.empty((m, m)), np.empty((m, m))
+    it, res = C.c_int32(), C.c_double()
+    _lib.check(ctx.lib.nk_sqrtm_spd(ctx.handle, P.ctypes.data, m, m, S.ctypes.data, Si.ctypes.data, C.byref(it), C.byref(res)))
+    ref = scipy.linalg.sqrtm(P).real
+    assert relf(S, ref) < 1e-11 and relf(S @ S, P) < 1e-12 and relf(Si @ S, np.eye(m)) < 1e-10
+    R = rng.standard_normal((m, m + 3))
+    X = np.empty_like(R)
+    _lib.check(ctx.lib.nk_solve_spd(ctx.handle, P.ctypes.data, m, m, R.ctypes.data, m + 3, m + 3, X.ctypes.data, m + 3))
+    assert relf(X, np.linalg.solve(P, R)) < 1e-10
+    bad = -np.eye(m)
+    with pytest.raises(_lib.NyskoopError):
+        _lib.check(ctx.lib.nk_solve_spd(ctx.handle, bad.ctypes.data, m, m, R.ctypes.data, m + 3, m + 3, X.ctypes.data, m + 3))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# a4-a14: fit / lift / predict against the reference's golden vectors
+# ---------------------------------------------------------------------------------------------------------------
+FITS = [
+    # file, p, tol operators, tol predict  (1e-6 = north-star bar; ill-conditioned fits are graded on predictions)
+    ("f1_cloth_rbf_wellcond.npz", 6, 1e-6, 1e-7),
+    ("f2_synth_rbf_d384.npz", 6, 1e-8, 1e-9),
+    ("f4_hjb_matern.npz", 1, 1e-6, 1e-7),
+    ("f1_cloth_rbf_illcond.npz", 6, 5e-3, 1e-4),
+    ("f3_duffing_matern.npz", 1, 5e-3, 1e-3),
+]
+
+
+def _fit(nk, O, name, g, p):
+    X, Y = g["X"].astype(np.float64), g["Y"].astype(np.float64)
+    d = Y.shape[1]
+    kern, _ = _kernels(nk, O, name, g["ls"], d)
+    reg = nk.KoopmanNystromRegressor(p, kernel=kern, gamma=float(g["gamma"]), m=len(g["idx"]))
+    reg.nystrom_centers_output = Y.T[:, g["idx"]]
+    assert reg.fit(X, Y) is None
+    return reg, X, Y, d
+
+
+@pytest.mark.parametrize("name,p,tol,tolp", FITS)
+def test_fit_lift_predict_vs_reference_golden(nk, O, golden, name, p, tol, tolp):
+    g = golden(name)
+    reg, X, Y, d = _fit(nk, O, name, g, p)
+    m = len(g["idx"])
+    assert reg.A.shape == (m, m) and reg.B.shape == (m, p) and reg.C.shape == (d, m) and reg.weights.shape == (d, m + p)
+    assert reg.A.dtype == np.float64 and reg.nystrom_centers_input is reg.nystrom_centers_output
+    errs = {nm: relf(got, g[nm]) for nm, got in (("A", reg.A), ("B", reg.B), ("C", reg.C), ("W", reg.weights))}
+    assert max(errs.values()) < tol, (name, errs, reg.fit_stats_)
+    q = g["q"]
+    lift = reg.lift(X.T[:d, q])
+    assert lift.shape == g["lift"].shape and relf(lift, g["lift"]) < max(tolp, 1e-8) * 10
+    pred = reg.predict(X[q])
+    assert pred.shape == g["predict"].shape and relf(pred, g["predict"]) < tolp, relf(pred, g["predict"])
+
+
+def test_rollout_forms_and_pickle(nk, O, golden):
+    g = golden("f1_cloth_rbf_wellcond.npz")
+    reg, X, Y, d = _fit(nk, O, "rbf", g, 6)
+    sim, Z = reg.rollout(g["test_traj"][:, 0], g["test_u"], return_lifted=True)
+    assert sim.shape == g["rollout"].shape and relf(sim, g["rollout"]) < 1e-6 and relf(Z, g["rollout_lifted"]) < 1e-6
+    from nys_koop_lqr_amd import harness
+    assert abs(harness.validate_dyn_sys(reg, g["test_traj"], g["test_u"]) - float(g["rmse_abs"])) < 1e-8
+    # batch form == single form
+    x0s = np.stack([g["test_traj"][:, 0], g["test_traj"][:, 5], g["test_traj"][:, 9]])
+    U = np.stack([g["test_u"].T] * 3)
+    xb = reg.rollout(x0s, U)
+    assert xb.shape == (3, g["test_u"].shape[1], d) and relf(xb[0].T, sim) < 1e-12
+    # pickling drops device handles; the un-pickled object rebuilds K_mm^{-1/2} from the landmarks
+    reg2 = pickle.loads(pickle.dumps(reg))
+    assert reg2._model is None and relf(reg2.predict(X[:9]), reg.predict(X[:9])) < 1e-10
+    g2 = golden("f2_synth_rbf_d384.npz")
+    reg, X, Y, d = _fit(nk, O, "rbf", g2, 6)
+    sim, Z = reg.rollout(g2["x0"], g2["Useq"], return_lifted=True)
+    assert relf(sim, g2["rollout"]) < 1e-6 and relf(Z, g2["rollout_lifted"]) < 1e-6  # north-star forecast bar
+    g3 = golden("f3_duffing_matern.npz")
+    reg, X, Y, d = _fit(nk, O, "matern", g3, 1)
+    r = harness.validate_dyn_sys(reg, g3["test_traj"], g3["test_u"], relative=True)
+    assert abs(r - float(g3["rmse_rel"])) < 2e-2 * float(g3["rmse_rel"])
+
+
+def test_fit_with_global_rng_and_row_ranges(nk, O, golden):
+    g = golden("f1_cloth_rbf_wellcond.npz")
+    X, Y = g["X"], g["Y"]
+    kern, okern = _kernels(nk, O, "rbf", g["ls"], 192)
+    np.random.seed(5)
+    reg = nk.KoopmanNystromRegressor(6, kernel=kern, gamma=1e-3, m=20)
+    reg.fit(X, Y)
+    np.random.seed(5)
+    idx = np.random.choice(np.arange(0, X.shape[0]), size=20, replace=False)  # regressors.py:130
+    assert np.array_equal(reg.nystrom_centers_output, Y.T[:, idx])
+    # two contiguous training ranges (a K-fold split) == fitting on the stacked copy
+    lo, hi = 101, 202
+    tr = np.r_[0:lo, hi:X.shape[0]]
+    a = nk.KoopmanNystromRegressor(6, kernel=kern, gamma=1e-3, m=20)
+    a.nystrom_centers_output = Y[tr].T[:, :20]
+    a.fit(X, Y, row_ranges=[(0, lo), (hi, X.shape[0])])
+    b = nk.KoopmanNystromRegressor(6, kernel=kern, gamma=1e-3, m=20)
+    b.nystrom_centers_output = Y[tr].T[:, :20]
+    b.fit(X[tr], Y[tr])
+    assert relf(a.A, b.A) < 1e-9 and relf(a.weights, b.weights) < 1e-9
+    ref = O.KoopmanNystromOracle(6, kernel=okern, gamma=1e-3, m=20)
+    ref.nystrom_centers_output = Y[tr].T[:, :20]
+    ref.fit(X[tr], Y[tr])
+    assert relf(a.weights, ref.weights) < 1e-6
+    assert abs(a.score_neg_rmse(X[lo:hi], Y[lo:hi]) - O.neg_rmse_score(Y[lo:hi], ref.predict(X[lo:hi]))) < 1e-9
+    with pytest.raises(ValueError):  # m > n, as np.random.choice raises in the reference
+        nk.KoopmanNystromRegressor(6, kernel=kern, gamma=1e-3, m=10 ** 6).fit(X, Y)
+    with pytest.raises(ValueError):  # lengthscale / data dimension mismatch
+        c = nk.KoopmanNystromRegressor(6, kernel=nk.ThreeDimensionalKernel(1, 1, 1, 10), gamma=1e-3, m=5)
+        c.fit(X, Y)
+
+
+def test_gridsearch_scores_vs_sklearn_driving_reference(nk, golden):
+    from nys_koop_lqr_amd import harness
+    g = golden("f5_cloth_gridsearch.npz")
+    X, Y, m = g["X"], g["Y"], int(g["m"])
+    cands = []
+    for c in range(g["split_scores"].shape[0]):
+        ls = g["cands"][g["order_kernel"][c]]
+        cands.append(dict(kernel=nk.ThreeDimensionalKernel(*ls, 192), gamma=float(g["order_gamma"][c]), m=m))
+    np.random.seed(int(g["seed"]))
+    res = harness.grid_search_cv(X, Y, 6, cands, n_splits=5)
+    assert np.max(np.abs(res["split_scores"] - g["split_scores"]) / np.abs(g["split_scores"])) < 1e-5
+    assert res["best_index"] == int(g["best_index"])
+
+
+def test_cloth_known_answer_gain_and_closed_loop(nk, O, golden):
+    """Whole path on the reference authors' own artefact: seed -> landmarks -> HIP fit -> host DARE -> gain vs the
+    shipped K_lqr_seed_0.csv.  cond(inner) ~ 8e13 and the reference's lstsq (LAPACK gelsd) leaves a relative
+    residual of 7e-5 on this system while Cholesky / LU / gelsy / plain SVD all agree with each other (residual
+    5e-7) and sit 1.6e-1 away from gelsd's `sol` (tools/gelsd_accuracy_note.py).  The reference's operators
+    therefore carry gelsd's own error: any accurate solver lands 3e-2 from its A and 3e-4 from its predictions
+    (the oracle's Cholesky mode shows the same numbers), so the bars here are 2e-3 on predictions, 1e-1 on the
+    gain, and tight agreement of the device closed loop with the oracle loop on the same operators."""
+    g = golden("f6_cloth_known_gain.npz")
+    tr, u = g["trajs"], g["inputs"]
+    X = np.ascontiguousarray(np.hstack([np.vstack((tr[i][:, :-1], u[i][:, :-1])) for i in range(30)]).T)
+    Y = np.ascontiguousarray(np.hstack([tr[i][:, 1:] for i in range(30)]).T)
+    np.random.seed(0)
+    reg = nk.KoopmanNystromRegressor(6, kernel=nk.ThreeDimensionalKernel(10, 10, 10, 192), gamma=1e-7, m=100)
+    reg.fit(X, Y)
+    np.random.seed(0)
+    ref = O.KoopmanNystromOracle(6, kernel=O.ThreeDimensionalKernel(10, 10, 10, 192), gamma=1e-7, m=100)
+    ref.fit(X, Y)
+    assert relf(reg.predict(X[:200]), ref.predict(X[:200])) < 2e-3
+    K = reg.solve_lqr(c=0.005)
+    from nys_koop_lqr_amd.lqr import cloth_gain_for_simulator
+    assert relf(cloth_gain_for_simulator(K), g["K_lqr_seed_0"]) < 1e-1
+    # closed loop in lifted space: device loop == oracle loop on the same (A,B,C,K)
+    x0 = tr[0][:, :1]
+    phi0, phir = reg.lift(x0), reg.lift(tr[0][:, 50:51])
+    xs, us = reg.closed_loop(K, phi0, phir, 60)
+    xo, uo = O.lqr_closed_loop_lifted(reg.A, reg.B, reg.C, K, phi0, phir, 60)
+    assert relf(xs, xo) < 1e-9 and relf(us, uo) < 1e-7
