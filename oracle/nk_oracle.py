@@ -125,6 +125,9 @@ class KoopmanNystromOracle:
 
     # regressors.py:122-169
     def fit(self, X, Y):
+        import time
+        t0 = time.perf_counter()
+        tm = self.timings = dict(kernel_n=0.0, gram_n=0.0, fixed=0.0)
         X = X.T
         Y = Y.T
         n_states = X.shape[0] - self.n_inputs
@@ -143,14 +146,18 @@ class KoopmanNystromOracle:
             Sinv = None
         else:
             S, Sinv = _sqrtm_eigh(K_mm_out)
+        t1 = time.perf_counter()
         K_mn_out = k(Zo.T, Y.T)  # :141
         K_mn_in_x = k(Zi.T, X[:n_states, :].T)  # :142
+        tm["kernel_n"] += time.perf_counter() - t1
         K_mm_in_x = k(Zi.T, Zi.T) + self.jitter * eye_m  # :143
         K_mm_in_x_out = k(Zi.T, Zo.T)  # :144 (no jitter)
+        t1 = time.perf_counter()
         K_mn_in = np.vstack((K_mn_in_x, X[n_states:, :]))  # :147
         K_mm_in = scipy.linalg.block_diag(K_mm_in_x, np.eye(self.n_inputs))  # :148
         inner = K_mn_in @ K_mn_in.T + gamma_n * K_mm_in  # :151
         cross = K_mn_out @ K_mn_in.T
+        tm["gram_n"] += time.perf_counter() - t1
         if self.faithful:
             right = scipy.linalg.block_diag(
                 scipy.linalg.solve(S, K_mm_in_x_out.T, assume_a="her").T, np.eye(self.n_inputs))  # :152
@@ -163,9 +170,11 @@ class KoopmanNystromOracle:
         G = left @ sol  # :156
         self.A = G[:, : self.m]  # :158
         self.B = G[:, self.m:]  # :159
+        t1 = time.perf_counter()
         inner_rec = gamma_n * K_mm_out + K_mn_out @ K_mn_out.T  # :162
-        right_rec = scipy.linalg.sqrtm(K_mm_out).real if self.faithful else S  # :163
         left_rec = Y @ K_mn_out.T  # :164
+        tm["gram_n"] += time.perf_counter() - t1
+        right_rec = scipy.linalg.sqrtm(K_mm_out).real if self.faithful else S  # :163
         if self.faithful:
             sol_rec = scipy.linalg.lstsq(inner_rec, right_rec)[0]  # :165
         else:
@@ -173,6 +182,8 @@ class KoopmanNystromOracle:
         self.C = left_rec @ sol_rec  # :166
         self.weights = self.C @ G  # :167-169
         self._S, self._Sinv = S, Sinv
+        tm["total"] = time.perf_counter() - t0
+        tm["fixed"] = tm["total"] - tm["kernel_n"] - tm["gram_n"]  # everything that does not grow with n
         # intermediates kept for stage-level parity tests of the HIP path
         self.stages = dict(K_mm=K_mm_out, S=S, inner=inner, cross=cross, inner_rec=inner_rec,
                            left_rec=left_rec)
