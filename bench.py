@@ -47,10 +47,10 @@ def make_c4(n, d, p, m, seed=1234):
 
 
 def gram_flops_syrk(n, m, p, d):
-    """Algorithmic flop of the three big Gram launches with the symmetry of the two SYRKs exploited
-    (2.07e12 per fit at C4 including the d x m product, which is a separate small launch)."""
+    """Algorithmic flop of the fused Gram launch with the symmetry of the two SYRKs exploited
+    (the 2.07e12-per-fit figure minus the distance flops): (m+p)(m+p+1)n + 2m(m+p)n + m(m+1)n + 2dmn."""
     mp = m + p
-    return mp * (mp + 1) * n, 2.0 * m * mp * n, m * (m + 1) * n
+    return mp * (mp + 1) * n + 2.0 * m * mp * n + m * (m + 1) * n + 2.0 * d * m * n
 
 
 def cpu_baseline(X, Y, idx, ls, gamma, p, sample_rows, threads):
@@ -150,8 +150,8 @@ def main():
         ms_step = elapsed / args.steps * 1e3
         value = world * args.steps / elapsed
         avg = lambda k: float(np.mean([st[k] for st in stats]))
-        f1, f2, f3 = gram_flops_syrk(n, m, p, d)
-        flops_per_launch = (f1 + f2 + f3) / 3.0
+        launches = max(int(stats[-1]["gram_kernel_launches"]), 1)
+        flops_per_launch = gram_flops_syrk(n, m, p, d) / launches  # one fused launch when operands are aligned
         achieved = flops_per_launch / (avg("ms_gram_kernel_avg") * 1e-3) / 1e12
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "gram_traffic.json")
@@ -173,12 +173,13 @@ def main():
                        "parallelism": "1 process/GPU, independent fits per rank, RCCL all-gather of per-fit scalars"},
             "stages_ms": {k: avg(k) for k in ("ms_total", "ms_kmat", "ms_gram", "ms_sqrt", "ms_solve")},
             "sqrt_iters": int(stats[-1]["sqrt_iters"]),
-            "roofline": {"bound": "mfma", "kernel": "nk::gemm_f64_kernel<true,false> (Gram / cross-Gram over n)",
+            "roofline": {"bound": "mfma", "kernel": "nk::gemm_tn_f64_kernel (fused Gram / cross-Gram launch over n)",
                          "achieved": achieved, "peak": MFMA_F64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / MFMA_F64_PEAK_TFLOPS, "traffic": traffic,
                          "flops_per_launch": flops_per_launch, "avg_launch_ms": avg("ms_gram_kernel_avg"),
-                         "note": "algorithmic flop with SYRK symmetry exploited: (m+p)(m+p+1)n, 2m(m+p)n, m(m+1)n over "
-                                 "3 launches; split-K reduce kernels excluded from the launch time"},
+                         "launches_per_fit": launches,
+                         "note": "algorithmic flop with SYRK symmetry exploited: (m+p)(m+p+1)n + 2m(m+p)n + m(m+1)n + 2dmn "
+                                 "in one fused launch; the split-K reduce kernel is excluded from the launch time"},
         }
         if world == 1 and not args.no_cpu_baseline:
             base, ref = cpu_baseline(X, Y, idx, 20.0, 1e-6, p, min(args.cpu_sample_rows, n), args.cpu_threads)

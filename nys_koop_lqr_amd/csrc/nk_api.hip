@@ -319,6 +319,7 @@ int nk_destroy(nk_ctx* ctx) {
   for (auto& c : ctx->arena.chunks) (void)hipFree(c.base);
   (void)hipFree(ctx->d_info);
   (void)hipFree(ctx->d_scalars);
+  if (ctx->d_zeros) (void)hipFree(ctx->d_zeros);
   (void)hipHostFree(ctx->h_scalars);
   for (int i = 0; i < 16; ++i) (void)hipEventDestroy(ctx->ev[i]);
   (void)hipStreamDestroy(ctx->stream);
@@ -435,27 +436,63 @@ int nk_nystrom_fit(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int64
   }
   NK_HIP(hipEventRecord(ev[2], ctx->stream));
 
-  // ---- Gram contractions over the samples (regressors.py:151,153,162,164) ------------------------------------------
-  double *G1 = nullptr, *G2 = nullptr, *G3 = nullptr, *G4 = nullptr;
+  // ---- Gram contractions over the samples (regressors.py:151,153,162,164): ONE fused launch ------------------------
+  //   G1 = Phi_in^T Phi_in (symmetric), G2t = Phi_in^T Phi_out (= cross^T), G3 = Phi_out^T Phi_out (symmetric),
+  //   G4t = Phi_out^T Y (= left_rec^T)
+  double *G1 = nullptr, *G2t = nullptr, *G3 = nullptr, *G4t = nullptr;
+  const int64_t ldd = d + (d & 1);
   NK_TRY(arena_alloc_t(ctx, (size_t)mp * mp, &G1));
-  NK_TRY(arena_alloc_t(ctx, (size_t)m * mp, &G2));
+  NK_TRY(arena_alloc_t(ctx, (size_t)mp * m, &G2t));
   NK_TRY(arena_alloc_t(ctx, (size_t)m * m, &G3));
-  NK_TRY(arena_alloc_t(ctx, (size_t)d * m, &G4));
-  GemmOpts sym;
-  sym.tri = TRI_UPPER_MIRROR;
-  float ms_g[3] = {0.f, 0.f, 0.f};
+  NK_TRY(arena_alloc_t(ctx, (size_t)m * ldd, &G4t));
+  float ms_gram_kernel = 0.f;
+  int gram_launches = 0;
   const bool timed = stats != nullptr;
-  NK_TRY(launch_gemm(ctx, true, false, mp, mp, n_eff, 1.0, F, ldf, F, ldf, 0.0, G1, mp, sym, timed ? &ms_g[0] : nullptr));
-  NK_TRY(launch_gemm(ctx, true, false, m, mp, n_eff, 1.0, F + off_out, ldf, F, ldf, 0.0, G2, mp, GemmOpts(),
-                     timed ? &ms_g[1] : nullptr));
-  NK_TRY(launch_gemm(ctx, true, false, m, m, n_eff, 1.0, F + off_out, ldf, F + off_out, ldf, 0.0, G3, m, sym,
-                     timed ? &ms_g[2] : nullptr));
-  o = 0;
-  for (size_t i = 0; i < rng.size(); i += 2) {
-    const int64_t b = rng[i], len = rng[i + 1] - rng[i];
-    NK_TRY(launch_gemm(ctx, true, false, d, m, len, 1.0, y.ptr + b * y.ld, y.ld, F + o * ldf + off_out, ldf,
-                       i == 0 ? 0.0 : 1.0, G4, m));
-    o += len;
+  {
+    TnProblem pr[4];
+    pr[0].A = F; pr[0].B = F; pr[0].lda = pr[0].ldb = ldf; pr[0].M = pr[0].N = mp; pr[0].C = G1; pr[0].ldc = mp;
+    pr[0].tri = TRI_UPPER_MIRROR;
+    pr[1].A = F; pr[1].B = F + off_out; pr[1].lda = pr[1].ldb = ldf; pr[1].M = mp; pr[1].N = m; pr[1].C = G2t;
+    pr[1].ldc = m;
+    pr[2].A = F + off_out; pr[2].B = F + off_out; pr[2].lda = pr[2].ldb = ldf; pr[2].M = pr[2].N = m; pr[2].C = G3;
+    pr[2].ldc = m; pr[2].tri = TRI_UPPER_MIRROR;
+    pr[3].A = F + off_out; pr[3].lda = ldf; pr[3].M = m; pr[3].N = d; pr[3].C = G4t; pr[3].ldc = ldd;
+    pr[3].B = y.ptr + rng[0] * y.ld; pr[3].ldb = y.ld;
+    const bool single = rng.size() == 2;
+    bool fast = tn_fast_ok(pr[0]) && tn_fast_ok(pr[1]) && tn_fast_ok(pr[2]);
+    const bool fast_y = fast && tn_fast_ok(pr[3]);
+    if (fast) {
+      const int np = (single && fast_y) ? 4 : 3;
+      NK_TRY(launch_gemm_tn_multi(ctx, pr, np, n_eff, 0, timed ? &ms_gram_kernel : nullptr));
+      gram_launches = 1;
+      if (np == 3) {
+        int64_t oo = 0;
+        for (size_t i = 0; i < rng.size(); i += 2) {
+          const int64_t b = rng[i], len = rng[i + 1] - rng[i];
+          NK_TRY(launch_gemm(ctx, true, false, m, d, len, 1.0, F + oo * ldf + off_out, ldf, y.ptr + b * y.ld, y.ld,
+                             i == 0 ? 0.0 : 1.0, G4t, ldd));
+          oo += len;
+        }
+      }
+    } else {  // unaligned operands (odd m+p): generic engine
+      GemmOpts sym;
+      sym.tri = TRI_UPPER_MIRROR;
+      float t3[3] = {0.f, 0.f, 0.f};
+      NK_TRY(launch_gemm(ctx, true, false, mp, mp, n_eff, 1.0, F, ldf, F, ldf, 0.0, G1, mp, sym, timed ? &t3[0] : nullptr));
+      NK_TRY(launch_gemm(ctx, true, false, mp, m, n_eff, 1.0, F, ldf, F + off_out, ldf, 0.0, G2t, m, GemmOpts(),
+                         timed ? &t3[1] : nullptr));
+      NK_TRY(launch_gemm(ctx, true, false, m, m, n_eff, 1.0, F + off_out, ldf, F + off_out, ldf, 0.0, G3, m, sym,
+                         timed ? &t3[2] : nullptr));
+      ms_gram_kernel = t3[0] + t3[1] + t3[2];
+      gram_launches = 3;
+      int64_t oo = 0;
+      for (size_t i = 0; i < rng.size(); i += 2) {
+        const int64_t b = rng[i], len = rng[i + 1] - rng[i];
+        NK_TRY(launch_gemm(ctx, true, false, m, d, len, 1.0, F + oo * ldf + off_out, ldf, y.ptr + b * y.ld, y.ld,
+                           i == 0 ? 0.0 : 1.0, G4t, ldd));
+        oo += len;
+      }
+    }
   }
   NK_HIP(hipEventRecord(ev[3], ctx->stream));
 
@@ -466,29 +503,41 @@ int nk_nystrom_fit(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int64
   NK_HIP(hipEventRecord(ev[4], ctx->stream));
 
   // ---- [A B] = S^-1 (Phi_out Phi_in^T) inner^-1 blkdiag(K_xo S^-1, I)   (regressors.py:151-159) ------------------------
+  // all products are written as P^T Q with P stored contraction-major (the fast TN engine); explicit transposes
+  // where the left factor is not exactly symmetric
   NK_TRY(launch_axpby2d(ctx, gamma_n, Kj_in, m, 1.0, G1, mp, m, m));               // inner = G1 + gamma_n*blkdiag(K, I)
   if (p > 0) NK_TRY(launch_add_diag(ctx, G1 + (int64_t)m * mp + m, mp, p, gamma_n));
-  double *right = nullptr, *Linv = nullptr, *T2 = nullptr;
+  double *right = nullptr, *Linv = nullptr, *T2 = nullptr, *Sinvt = nullptr, *Kxot = nullptr;
   const int nblk = (mp + CHOL_NB - 1) / CHOL_NB;
   NK_TRY(arena_alloc_t(ctx, (size_t)mp * mp, &right));
   NK_TRY(arena_alloc_t(ctx, (size_t)nblk * CHOL_NB * CHOL_NB, &Linv));
   NK_TRY(arena_alloc_t(ctx, (size_t)m * mp, &T2));
+  NK_TRY(arena_alloc_t(ctx, (size_t)m * m, &Sinvt));
+  NK_TRY(launch_transpose(ctx, mdl->Sinv, m, Sinvt, m, m, m));
+  if (same_centers) {
+    Kxot = Kxo;  // K(Z,Z) is bitwise symmetric
+  } else {
+    NK_TRY(arena_alloc_t(ctx, (size_t)m * m, &Kxot));
+    NK_TRY(launch_transpose(ctx, Kxo, m, Kxot, m, m, m));
+  }
   NK_TRY(launch_fill(ctx, right, mp, mp, mp, 0.0));
-  NK_TRY(launch_gemm(ctx, false, false, m, m, m, 1.0, Kxo, m, mdl->Sinv, m, 0.0, right, mp));  // K_xo S^-1
+  NK_TRY(launch_gemm(ctx, true, false, m, m, m, 1.0, Kxot, m, mdl->Sinv, m, 0.0, right, mp));    // K_xo S^-1
   if (p > 0) NK_TRY(launch_add_diag(ctx, right + (int64_t)m * mp + m, mp, p, 1.0));
   NK_TRY(cholesky_lower(ctx, G1, mp, mp, Linv));
-  NK_TRY(cholesky_solve(ctx, G1, mp, mp, Linv, right, mp, mp));                                 // sol
-  NK_TRY(launch_gemm(ctx, false, false, m, mp, mp, 1.0, G2, mp, right, mp, 0.0, T2, mp));       // cross * sol
-  NK_TRY(launch_gemm(ctx, false, false, m, mp, m, 1.0, mdl->Sinv, m, T2, mp, 0.0, mdl->A, mp)); // G = S^-1 (.)
+  NK_TRY(cholesky_solve(ctx, G1, mp, mp, Linv, right, mp, mp));                                   // sol
+  NK_TRY(launch_gemm(ctx, true, false, m, mp, mp, 1.0, G2t, m, right, mp, 0.0, T2, mp));          // cross * sol
+  NK_TRY(launch_gemm(ctx, true, false, m, mp, m, 1.0, Sinvt, m, T2, mp, 0.0, mdl->A, mp));        // G = S^-1 (.)
   // ---- C = (Y Phi_out^T) (gamma_n K + Phi_out Phi_out^T)^-1 S   (regressors.py:162-166) ---------------------------------
   NK_TRY(launch_axpby2d(ctx, gamma_n, Kj, m, 1.0, G3, m, m, m));
-  double* sol_rec = nullptr;
+  double *sol_rec = nullptr, *Ct = nullptr;
   NK_TRY(arena_alloc_t(ctx, (size_t)m * m, &sol_rec));
+  NK_TRY(arena_alloc_t(ctx, (size_t)m * ldd, &Ct));
   NK_TRY(launch_copy2d(ctx, mdl->S, m, sol_rec, m, m, m));
   NK_TRY(cholesky_lower(ctx, G3, m, m, Linv));
   NK_TRY(cholesky_solve(ctx, G3, m, m, Linv, sol_rec, m, m));
-  NK_TRY(launch_gemm(ctx, false, false, d, m, m, 1.0, G4, m, sol_rec, m, 0.0, mdl->C, m));
-  NK_TRY(launch_gemm(ctx, false, false, d, mp, m, 1.0, mdl->C, m, mdl->A, mp, 0.0, mdl->W, mp));  // W = C G (:167)
+  NK_TRY(launch_gemm(ctx, true, false, d, m, m, 1.0, G4t, ldd, sol_rec, m, 0.0, mdl->C, m));      // C = left_rec sol_rec
+  NK_TRY(launch_transpose(ctx, mdl->C, m, Ct, ldd, d, m));
+  NK_TRY(launch_gemm(ctx, true, false, d, mp, m, 1.0, Ct, ldd, mdl->A, mp, 0.0, mdl->W, mp));     // W = C G (:167)
   NK_HIP(hipEventRecord(ev[5], ctx->stream));
   NK_HIP(hipStreamSynchronize(ctx->stream));
   mdl->has_ops = true;
@@ -501,8 +550,8 @@ int nk_nystrom_fit(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int64
     stats->ms_gram = ev_ms(ctx, 2, 3);
     stats->ms_sqrt = ev_ms(ctx, 3, 4);
     stats->ms_solve = ev_ms(ctx, 4, 5);
-    stats->ms_gram_kernel_avg = (ms_g[0] + ms_g[1] + ms_g[2]) / 3.0;
-    stats->gram_kernel_launches = 3;
+    stats->ms_gram_kernel_avg = gram_launches ? ms_gram_kernel / gram_launches : 0.0;
+    stats->gram_kernel_launches = gram_launches;
     stats->sqrt_iters = it;
     stats->sqrt_residual = resid;
     const double ne = (double)n_eff;

@@ -61,6 +61,7 @@ struct nk_ctx {
   int* d_info = nullptr;       // device flag for factorisation failures
   double* d_scalars = nullptr; // small device scratch for reductions (64 doubles)
   double* h_scalars = nullptr; // pinned host mirror
+  double* d_zeros = nullptr;   // 4 KiB zero page (K-tail rows of the LDS-DMA GEMM)
   hipEvent_t ev[16];
   int num_cu = 256;
 };
@@ -127,4 +128,23 @@ int cholesky_solve(nk_ctx* ctx, const double* L, int64_t ldl, int m, const doubl
                    int nrhs);  // R <- (L L^T)^{-1} R in place
 constexpr int CHOL_NB = 64;
 
+}  // namespace nk
+
+namespace nk {
+// ---- fast TN multi-problem GEMM (LDS-DMA staged), see nk_gemm_tn.hip -------------------------------------------
+// C_p[M_p x N_p] = alpha_p * A_p^T B_p + beta_p * C_p for up to 4 problems that share the contraction length K:
+// A_p stored K x M_p (lda), B_p stored K x N_p (ldb).  One launch covers every 128x128 tile of every problem.
+struct TnProblem {
+  const double* A = nullptr;
+  const double* B = nullptr;
+  double* C = nullptr;
+  int64_t lda = 0, ldb = 0, ldc = 0;
+  int M = 0, N = 0;
+  int tri = TRI_FULL;  // TRI_UPPER_MIRROR for symmetric products (A == B)
+  double alpha = 1.0, beta = 0.0;
+};
+bool tn_fast_ok(const TnProblem& p);  // alignment / leading-dimension requirements of the LDS-DMA path
+int launch_gemm_tn_multi(nk_ctx* ctx, const TnProblem* probs, int nprob, int64_t K, int splitk /*0=auto*/,
+                         float* ms_kernel = nullptr);
+int launch_transpose(nk_ctx* ctx, const double* src, int64_t lds, double* dst, int64_t ldd, int rows, int cols);
 }  // namespace nk

@@ -262,6 +262,13 @@ int launch_gemm(nk_ctx* ctx, bool transA, bool transB, int64_t M, int64_t N, int
                 float* ms_kernel) {
   if (M <= 0 || N <= 0) return NK_OK;
   NK_REQUIRE(M < (1 << 30) && N < (1 << 30) && K < (1LL << 31) && K >= 0, "nk_gemm: dimension out of range");
+  if (transA && !transB && opts.tri != TRI_LOWER && opts.splitk == 0 && K >= 128) {
+    // contraction-major operands: LDS-DMA engine (nk_gemm_tn.hip) when the alignment contract holds
+    TnProblem tp;
+    tp.A = A; tp.B = B; tp.C = C; tp.lda = lda; tp.ldb = ldb; tp.ldc = ldc; tp.M = (int)M; tp.N = (int)N;
+    tp.tri = opts.tri; tp.alpha = alpha; tp.beta = beta;
+    if (tn_fast_ok(tp) && (opts.tri == TRI_FULL || M == N)) return launch_gemm_tn_multi(ctx, &tp, 1, K, 0, ms_kernel);
+  }
   GemmParams p;
   p.A = A; p.B = B; p.C = C; p.slab = nullptr;
   p.lda = lda; p.ldb = ldb; p.ldc = ldc;

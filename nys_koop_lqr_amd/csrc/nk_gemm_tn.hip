@@ -1,0 +1,321 @@
+// Fast fp64 "TN" GEMM for gfx950: C = A^T B with both operands stored contraction-major (rows = k), i.e. the layout of
+// every big product of the fit: the Gram contractions over the n samples of the sample-major feature matrix
+// F = [K_nm_in | U | K_nm_out] (regressors.py:151,153,162,164) and, with explicit transposes, the O(m^3) products.
+//
+// Differences from the generic engine (nk_gemm.hip):
+//   * global -> LDS by LDS-DMA (global_load_lds_dwordx4): one wave instruction moves one 128-double k-row (1 KiB)
+//     straight into the padded LDS image, so there is no VGPR staging, no ds_write and no per-element branching;
+//     out-of-range columns are clamped to valid addresses (their products land in accumulator rows/columns that are
+//     never stored), rows past the K range are redirected to a zero page;
+//   * the DMA for k-step t+1 is issued right after the barrier that retires step t-1 and stays in flight during
+//     the 64 MFMAs of step t (one barrier per step);
+//   * up to 4 problems that share K are fused into ONE launch (the four Gram products of a fit), all 128x128 tiles
+//     of all problems x splitk K-slices, slice = blockIdx % splitk (a multiple of 8 => one K range per XCD, panels
+//     shared through that XCD's L2), which removes the per-launch tails;
+//   * partial tiles go to a slab [tile][slice][128][128]; a second kernel sums the slices in a fixed order and
+//     applies alpha/beta, bounds and the symmetric mirror (deterministic; no float atomics).
+#include "nk_common.h"
+
+namespace nk {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+constexpr int TBM = 128, TBK = 16;
+constexpr int TSTRIDE = 144;                               // doubles per LDS row: conflict-free ds_read_b64 operand fetch
+constexpr int TSTAGE = 2 * TBK * TSTRIDE;                  // doubles per pipeline stage (A rows then B rows)
+constexpr int TN_LDS_BYTES = 2 * TSTAGE * 8;               // two stages
+constexpr int TN_MAXP = 4;
+
+struct TnDev {
+  const double* A;
+  const double* B;
+  int64_t lda, ldb;
+  int M, N;
+  int tiles_n;     // tiles along N
+  int tri;
+  int tile_begin;  // first global tile index of this problem
+};
+struct TnParams {
+  TnDev p[TN_MAXP];
+  int nprob;
+  int ntiles;
+  int K, splitk, klen;
+  const double* zeros;  // >= 1 KiB of zeros
+  double* slab;
+};
+
+__device__ __forceinline__ void dma_row(const double* gsrc, double* lds_row) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_row, 16, 0, 0);
+}
+
+__global__ void __launch_bounds__(256, 2) gemm_tn_f64_kernel(TnParams P) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int split = blockIdx.x % P.splitk;
+  const int gt = blockIdx.x / P.splitk;
+  int pi = 0;
+#pragma unroll
+  for (int q = 1; q < TN_MAXP; ++q)
+    if (q < P.nprob && gt >= P.p[q].tile_begin) pi = q;
+  const TnDev pr = P.p[pi];
+  int tm, tn;
+  {
+    const int t = gt - pr.tile_begin;
+    if (pr.tri == TRI_FULL) {
+      tm = t / pr.tiles_n;
+      tn = t - tm * pr.tiles_n;
+    } else {  // upper triangle, row-major enumeration
+      int row = 0, rem = t;
+      while (rem >= pr.tiles_n - row) {
+        rem -= pr.tiles_n - row;
+        ++row;
+      }
+      tm = row;
+      tn = row + rem;
+    }
+  }
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int kbeg = split * P.klen;
+  const int kend = min(P.K, kbeg + P.klen);
+  const int ktiles = kend > kbeg ? (kend - kbeg + TBK - 1) / TBK : 0;
+
+  // per-lane source columns (2 doubles per lane), clamped into the valid, 16-byte aligned range
+  const int ca = min(tm * TBM + lane * 2, (pr.M - 1) & ~1);
+  const int cb = min(tn * TBM + lane * 2, (pr.N - 1) & ~1);
+  const double* zsrc = P.zeros + lane * 2;
+
+  // wave w moves k-rows w, w+4, w+8, w+12 of the A panel and of the B panel
+  auto issue = [&](int kt, int stage) {
+    double* sa = smem + stage * TSTAGE;
+    double* sb = sa + TBK * TSTRIDE;
+    const int k0 = kbeg + kt * TBK;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int r = wave + 4 * q;
+      const int k = k0 + r;
+      const bool ok = k < kend;
+      const double* ga = ok ? pr.A + (int64_t)k * pr.lda + ca : zsrc;
+      const double* gb = ok ? pr.B + (int64_t)k * pr.ldb + cb : zsrc;
+      dma_row(ga, sa + r * TSTRIDE);
+      dma_row(gb, sb + r * TSTRIDE);
+    }
+  };
+
+  d4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
+
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r16 = lane & 15, g4 = lane >> 4;
+
+  if (ktiles > 0) issue(0, 0);
+  for (int kt = 0; kt < ktiles; ++kt) {
+    const int st = kt & 1;
+    // my DMAs for step kt have landed; after the barrier everybody's have, and everybody is done reading stage st^1
+    __syncthreads();
+    if (kt + 1 < ktiles) issue(kt + 1, st ^ 1);
+    const double* a_base = smem + st * TSTAGE + wm * 64 + r16;
+    const double* b_base = smem + st * TSTAGE + TBK * TSTRIDE + wn * 64 + r16;
+#pragma unroll
+    for (int ks = 0; ks < TBK / 4; ++ks) {
+      double a[4], b[4];
+      const int krow = (ks * 4 + g4) * TSTRIDE;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = a_base[krow + i * 16];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = b_base[krow + j * 16];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  // raw 128x128 partial tile -> slab[(tile*splitk + split)]
+  double* out = P.slab + ((int64_t)gt * P.splitk + split) * (TBM * TBM);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int row = wm * 64 + i * 16 + g4 + 4 * reg;
+        const int col = wn * 64 + j * 16 + r16;
+        out[row * TBM + col] = acc[i][j][reg];
+      }
+}
+
+struct TnRed {
+  double* C;
+  int64_t ldc;
+  int M, N, tiles_n, tri, tile_begin;
+  double alpha, beta;
+};
+struct TnRedParams {
+  TnRed p[TN_MAXP];
+  int nprob, splitk;
+  const double* slab;
+};
+
+// one workgroup per tile: C = alpha * sum_s slab[tile][s] + beta * C (bounds, mirror)
+__global__ void __launch_bounds__(256) gemm_tn_reduce_kernel(TnRedParams P) {
+  const int gt = blockIdx.x;
+  int pi = 0;
+#pragma unroll
+  for (int q = 1; q < TN_MAXP; ++q)
+    if (q < P.nprob && gt >= P.p[q].tile_begin) pi = q;
+  const TnRed pr = P.p[pi];
+  int tm, tn;
+  {
+    const int t = gt - pr.tile_begin;
+    if (pr.tri == TRI_FULL) {
+      tm = t / pr.tiles_n;
+      tn = t - tm * pr.tiles_n;
+    } else {
+      int row = 0, rem = t;
+      while (rem >= pr.tiles_n - row) {
+        rem -= pr.tiles_n - row;
+        ++row;
+      }
+      tm = row;
+      tn = row + rem;
+    }
+  }
+  const double* base = P.slab + (int64_t)gt * P.splitk * (TBM * TBM);
+  const bool mirror = pr.tri == TRI_UPPER_MIRROR && tm != tn;
+  for (int e = threadIdx.x; e < TBM * TBM; e += 256) {
+    const int r = e >> 7, c = e & 127;
+    const int row = tm * TBM + r, col = tn * TBM + c;
+    if (row >= pr.M || col >= pr.N) continue;
+    double s = 0.0;
+    for (int k = 0; k < P.splitk; ++k) s += base[(int64_t)k * (TBM * TBM) + e];
+    double v = pr.alpha * s;
+    if (pr.beta != 0.0) v += pr.beta * pr.C[(int64_t)row * pr.ldc + col];
+    pr.C[(int64_t)row * pr.ldc + col] = v;
+    if (mirror) pr.C[(int64_t)col * pr.ldc + row] = v;
+  }
+}
+
+// 32x32 tiled transpose through LDS
+__global__ void __launch_bounds__(256) transpose_kernel(const double* __restrict__ src, int64_t lds_, double* __restrict__ dst,
+                                                        int64_t ldd, int rows, int cols) {
+  __shared__ double tile[32][33];
+  const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int r = ty; r < 32; r += 8) {
+    const int row = by + r, col = bx + tx;
+    if (row < rows && col < cols) tile[r][tx] = src[(int64_t)row * lds_ + col];
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int orow = bx + r, ocol = by + tx;  // dst[col][row]
+    if (orow < cols && ocol < rows) dst[(int64_t)orow * ldd + ocol] = tile[tx][r];
+  }
+}
+
+int launch_transpose(nk_ctx* ctx, const double* src, int64_t lds_, double* dst, int64_t ldd, int rows, int cols) {
+  if (rows <= 0 || cols <= 0) return NK_OK;
+  dim3 grid((cols + 31) / 32, (rows + 31) / 32);
+  hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, ctx->stream, src, lds_, dst, ldd, rows, cols);
+  NK_HIP(hipGetLastError());
+  return NK_OK;
+}
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+bool tn_fast_ok(const TnProblem& p) {
+  return p.M >= 2 && p.N >= 2 && aligned16(p.A) && aligned16(p.B) && p.lda % 2 == 0 && p.ldb % 2 == 0 &&
+         p.lda >= ((p.M + 1) & ~1) && p.ldb >= ((p.N + 1) & ~1);
+}
+
+static int ensure_zero_page(nk_ctx* ctx) {
+  if (ctx->d_zeros) return NK_OK;
+  NK_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->d_zeros), 4096));
+  NK_HIP(hipMemsetAsync(ctx->d_zeros, 0, 4096, ctx->stream));
+  return NK_OK;
+}
+
+int launch_gemm_tn_multi(nk_ctx* ctx, const TnProblem* probs, int nprob, int64_t K, int splitk, float* ms_kernel) {
+  NK_REQUIRE(nprob >= 1 && nprob <= TN_MAXP, "gemm_tn_multi: 1..4 problems");
+  NK_REQUIRE(K >= 0 && K < (1LL << 31), "gemm_tn_multi: K out of range");
+  NK_TRY(ensure_zero_page(ctx));
+  TnParams P;
+  TnRedParams R;
+  int ntiles = 0;
+  for (int q = 0; q < nprob; ++q) {
+    const TnProblem& s = probs[q];
+    NK_REQUIRE(tn_fast_ok(s), "gemm_tn_multi: problem %d violates the alignment contract", q);
+    NK_REQUIRE(s.tri == TRI_FULL || (s.tri == TRI_UPPER_MIRROR && s.M == s.N), "gemm_tn_multi: bad tri mode");
+    const int tmn = (s.M + TBM - 1) / TBM, tnn = (s.N + TBM - 1) / TBM;
+    TnDev& d = P.p[q];
+    d.A = s.A; d.B = s.B; d.lda = s.lda; d.ldb = s.ldb; d.M = s.M; d.N = s.N;
+    d.tiles_n = tnn; d.tri = s.tri; d.tile_begin = ntiles;
+    TnRed& r = R.p[q];
+    r.C = s.C; r.ldc = s.ldc; r.M = s.M; r.N = s.N; r.tiles_n = tnn; r.tri = s.tri; r.tile_begin = ntiles;
+    r.alpha = s.alpha; r.beta = s.beta;
+    ntiles += s.tri == TRI_FULL ? tmn * tnn : tmn * (tmn + 1) / 2;
+  }
+  for (int q = nprob; q < TN_MAXP; ++q) {
+    P.p[q] = P.p[0];
+    P.p[q].tile_begin = 1 << 30;
+    R.p[q] = R.p[0];
+    R.p[q].tile_begin = 1 << 30;
+  }
+  const int ktiles_total = (int)((K + TBK - 1) / TBK);
+  if (splitk <= 0) {
+    // Pick the number of K slices with a small cost model calibrated on MI355X (profiles/r01_*): a k-step costs
+    // 1.22 units per workgroup when two workgroups share a CU and 2.35 when a workgroup is alone on its CU (one wave
+    // per SIMD cannot hide the barrier + DMA latency); workgroups beyond 2/CU run as further rounds.  The slab
+    // round trip (write + read of ntiles*splitk tiles) is charged at ~4 TB/s.  Multiples of 8 keep one K range per
+    // XCD (panels shared through that XCD's L2) and get a small bonus.
+    const int slots = 2 * ctx->num_cu;
+    const int max_split = ktiles_total / 8 > 1 ? ktiles_total / 8 : 1;
+    double best = 1e300;
+    splitk = 1;
+    for (int c = 1; c <= 64 && c <= max_split; ++c) {
+      const int64_t wgs = (int64_t)ntiles * c;
+      const double steps = (double)((ktiles_total + c - 1) / c);
+      const int64_t full = wgs / slots, rem = wgs % slots;
+      double t = full * 2.44 * steps;
+      if (rem > 0) t += (rem <= ctx->num_cu ? 2.35 : 2.44) * steps;
+      t *= 4096.0;                                                      // cycles of MFMA per k-step and wave
+      t += (double)wgs * (TBM * TBM * 8.0 * 2.0) / 4.0e12 * 2.4e9;       // slab write + read, in cycles
+      t += 2000.0 * c / 8.0;                                            // mild preference for fewer slices
+      if (c % 8 == 0) t *= 0.97;
+      if (t < best) { best = t; splitk = c; }
+    }
+  }
+  P.nprob = nprob; P.ntiles = ntiles; P.K = (int)K; P.splitk = splitk;
+  P.klen = ((ktiles_total + splitk - 1) / splitk) * TBK;
+  if (P.klen == 0) P.klen = TBK;
+  P.zeros = ctx->d_zeros;
+  const ArenaMark mark = arena_mark(ctx);
+  double* slab = nullptr;
+  NK_TRY(arena_alloc_t(ctx, (size_t)ntiles * splitk * TBM * TBM, &slab));
+  P.slab = slab;
+  R.nprob = nprob; R.splitk = splitk; R.slab = slab;
+  static bool attr_set = false;
+  if (!attr_set) {
+    NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_f64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               TN_LDS_BYTES));
+    attr_set = true;
+  }
+  if (ms_kernel) NK_HIP(hipEventRecord(ctx->ev[14], ctx->stream));
+  hipLaunchKernelGGL(gemm_tn_f64_kernel, dim3((unsigned)(ntiles * splitk)), dim3(256), TN_LDS_BYTES, ctx->stream, P);
+  NK_HIP(hipGetLastError());
+  if (ms_kernel) NK_HIP(hipEventRecord(ctx->ev[15], ctx->stream));
+  hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, R);
+  NK_HIP(hipGetLastError());
+  if (ms_kernel) {
+    NK_HIP(hipEventSynchronize(ctx->ev[15]));
+    NK_HIP(hipEventElapsedTime(ms_kernel, ctx->ev[14], ctx->ev[15]));
+  }
+  arena_release(ctx, mark);
+  return NK_OK;
+}
+
+}  // namespace nk

@@ -81,6 +81,27 @@ __global__ void __launch_bounds__(256) frob_mi_partial_kernel(const double* __re
   __syncthreads();
   if (threadIdx.x == 0) partial[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
 }
+// per-block partial [sum of squares, trace]; finished by sum_partials_kernel on each half
+__global__ void __launch_bounds__(256) sumsq_trace_partial_kernel(const double* __restrict__ M, int64_t ldm, int n,
+                                                                  double* __restrict__ partial, int nblocks) {
+  __shared__ double sh[8];
+  const int64_t total = (int64_t)n * n;
+  double s = 0.0, t = 0.0;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = e / n, c = e - r * n;
+    const double v = M[r * ldm + c];
+    s = fma(v, v, s);
+    if (r == c) t += v;
+  }
+  s = wave_sum(s);
+  t = wave_sum(t);
+  if ((threadIdx.x & 63) == 0) { sh[threadIdx.x >> 6] = s; sh[4 + (threadIdx.x >> 6)] = t; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partial[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+    partial[nblocks + blockIdx.x] = sh[4] + sh[5] + sh[6] + sh[7];
+  }
+}
 __global__ void __launch_bounds__(256) sum_partials_kernel(const double* __restrict__ partial, int count,
                                                            double* __restrict__ out) {
   __shared__ double sh[4];
@@ -241,13 +262,14 @@ static int read_scalar(nk_ctx* ctx, const double* d_ptr, double* out) {
 int sqrtm_spd(nk_ctx* ctx, const double* P, int64_t ldp, int m, double* S, double* Sinv, int* iters, double* resid) {
   const ArenaMark mk = arena_mark(ctx);
   const size_t mm = (size_t)m * m;
-  double *Y = nullptr, *Z = nullptr, *Yn = nullptr, *Zn = nullptr, *M = nullptr, *T = nullptr;
+  double *Y = nullptr, *Z = nullptr, *Yn = nullptr, *Zn = nullptr, *M = nullptr, *T = nullptr, *Xt = nullptr;
   NK_TRY(arena_alloc_t(ctx, mm, &Y));
   NK_TRY(arena_alloc_t(ctx, mm, &Z));
   NK_TRY(arena_alloc_t(ctx, mm, &Yn));
   NK_TRY(arena_alloc_t(ctx, mm, &Zn));
   NK_TRY(arena_alloc_t(ctx, mm, &M));
   NK_TRY(arena_alloc_t(ctx, mm, &T));
+  NK_TRY(arena_alloc_t(ctx, mm, &Xt));
   double c = 0.0;
   NK_TRY(launch_max_abs_rowsum(ctx, P, ldp, m, ctx->d_scalars));
   NK_TRY(read_scalar(ctx, ctx->d_scalars, &c));
@@ -259,6 +281,31 @@ int sqrtm_spd(nk_ctx* ctx, const double* P, int64_t ldp, int m, double* S, doubl
   NK_TRY(launch_axpby2d(ctx, 1.0 / c, P, ldp, 0.0, Y, m, m, m));
   NK_TRY(launch_fill(ctx, Z, m, m, m, 0.0));
   NK_TRY(launch_add_diag(ctx, Z, m, m, 1.0));
+  // spectrum interval [a, b] of M_0 = Y_0: b = 1 (c = ||P||_inf bounds the largest eigenvalue); a = mean of the
+  // eigenvalues other than the dominant one, from trace and Frobenius norm -- an OVER-estimate of the smallest
+  // eigenvalue, which is the safe side: the scaled steps stay inside (0, 3) for every eigenvalue <= b, eigenvalues
+  // below a still grow by the same factor, and the scaling fades to 1 as a -> 1 (plain Newton-Schulz finish).
+  double a_lo = 1.0, b_hi = 1.0;
+  {
+    const int blocks = grid_for((int64_t)m * m, ctx->num_cu);
+    double* partial = nullptr;
+    NK_TRY(arena_alloc_t(ctx, (size_t)2 * blocks, &partial));
+    hipLaunchKernelGGL(sumsq_trace_partial_kernel, dim3(blocks), dim3(256), 0, ctx->stream, Y, (int64_t)m, m, partial,
+                       blocks);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, ctx->stream, partial, blocks, ctx->d_scalars + 1);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, ctx->stream, partial + blocks, blocks,
+                       ctx->d_scalars + 2);
+    NK_HIP(hipGetLastError());
+    NK_HIP(hipMemcpyAsync(ctx->h_scalars, ctx->d_scalars, 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    NK_HIP(hipStreamSynchronize(ctx->stream));
+    const double fro = std::sqrt(ctx->h_scalars[1]), tr = ctx->h_scalars[2];
+    const double lam1 = fro < 1.0 ? fro : 1.0;
+    if (m > 1 && tr > lam1) a_lo = (tr - lam1) / (m - 1);
+    else a_lo = tr / m * 1e-2;
+    if (!(a_lo > 0.0) || !std::isfinite(a_lo)) a_lo = 1e-12;
+    if (a_lo > 1.0) a_lo = 1.0;
+  }
+  auto p3 = [](double x) { return x * (3.0 - x) * (3.0 - x) * 0.25; };
   GemmOpts sym;
   sym.tri = TRI_UPPER_MIRROR;
   const int maxit = 100;
@@ -266,7 +313,11 @@ int sqrtm_spd(nk_ctx* ctx, const double* P, int64_t ldp, int m, double* S, doubl
   int it = 0;
   bool ok = false;
   for (; it < maxit; ++it) {
-    NK_TRY(launch_gemm(ctx, false, false, m, m, m, 1.0, Z, m, Y, m, 0.0, M, m, sym));
+    // every product is issued as P^T Q with P stored contraction-major (fast LDS-DMA engine); Z and Y are only
+    // symmetric up to rounding and must NOT be replaced by their transposes (that variant diverges), so the left
+    // factors are transposed explicitly (32 MB round trip, ~15 us)
+    NK_TRY(launch_transpose(ctx, Z, m, Xt, m, m, m));
+    NK_TRY(launch_gemm(ctx, true, false, m, m, m, 1.0, Xt, m, Y, m, 0.0, M, m, sym));
     NK_TRY(launch_frob_minus_identity(ctx, M, m, m, ctx->d_scalars));
     double r2 = 0.0;
     NK_TRY(read_scalar(ctx, ctx->d_scalars, &r2));
@@ -278,9 +329,20 @@ int sqrtm_spd(nk_ctx* ctx, const double* P, int64_t ldp, int m, double* S, doubl
       ok = true;
       break;
     }
-    NK_TRY(launch_scale_add_identity(ctx, -0.5, M, m, 1.5, T, m, m));
-    NK_TRY(launch_gemm(ctx, false, false, m, m, m, 1.0, Y, m, T, m, 0.0, Yn, m));
-    NK_TRY(launch_gemm(ctx, false, false, m, m, m, 1.0, T, m, Z, m, 0.0, Zn, m));
+    // scaled step: T = s (3I - s^2 M)/2 with s^2 = 3/(a + sqrt(ab) + b), which equalises p(s^2 a) = p(s^2 b) for
+    // p(x) = x (3-x)^2 / 4, the map the step applies to the eigenvalues of M; s -> 1 as a -> b = 1
+    const double s2 = 3.0 / (a_lo + std::sqrt(a_lo * b_hi) + b_hi);
+    const double sc = std::sqrt(s2);
+    {
+      const double xa = s2 * a_lo, xb = s2 * b_hi;
+      const double lo = p3(xa) < p3(xb) ? p3(xa) : p3(xb);
+      b_hi = (xa <= 1.0 && xb >= 1.0) ? 1.0 : (p3(xa) > p3(xb) ? p3(xa) : p3(xb));
+      a_lo = lo < b_hi ? lo : b_hi;
+    }
+    NK_TRY(launch_scale_add_identity(ctx, -0.5 * s2 * sc, M, m, 1.5 * sc, T, m, m));
+    NK_TRY(launch_transpose(ctx, Y, m, Xt, m, m, m));
+    NK_TRY(launch_gemm(ctx, true, false, m, m, m, 1.0, Xt, m, T, m, 0.0, Yn, m));   // Y T
+    NK_TRY(launch_gemm(ctx, true, false, m, m, m, 1.0, T, m, Z, m, 0.0, Zn, m));    // T Z (T is exactly symmetric)
     double* t = Y; Y = Yn; Yn = t;
     t = Z; Z = Zn; Zn = t;
   }
@@ -301,56 +363,8 @@ int sqrtm_spd(nk_ctx* ctx, const double* P, int64_t ldp, int m, double* S, doubl
 // ---------------------------------------------------------------------------------------------------------------
 // blocked Cholesky (lower) with inverted diagonal blocks
 // ---------------------------------------------------------------------------------------------------------------
-// One workgroup factorises a NB x NB diagonal block in LDS and inverts the factor.  Blocks shorter than NB are padded
-// with the identity.
-__global__ void __launch_bounds__(256) potrf_diag_kernel(double* __restrict__ A, int64_t lda, int nb,
-                                                         double* __restrict__ Linv, int* __restrict__ info, int blk) {
-  constexpr int NB = CHOL_NB;
-  __shared__ double L[NB][NB + 1];
-  __shared__ double X[NB][NB + 1];
-  const int tid = threadIdx.x;
-  for (int e = tid; e < NB * NB; e += 256) {
-    const int r = e / NB, c = e % NB;
-    double v = (r == c) ? 1.0 : 0.0;
-    if (r < nb && c < nb) v = (c <= r) ? A[(int64_t)r * lda + c] : 0.0;
-    L[r][c] = v;
-  }
-  __syncthreads();
-  for (int k = 0; k < nb; ++k) {
-    if (tid == 0) {
-      double dkk = L[k][k];
-      if (!(dkk > 0.0) || !isfinite(dkk)) {
-        if (atomicCAS(info, 0, blk * NB + k + 1) == 0) {}
-        dkk = 1.0;
-      }
-      L[k][k] = sqrt(dkk);
-    }
-    __syncthreads();
-    const double dk = L[k][k];
-    if (tid > k && tid < nb) L[tid][k] /= dk;
-    __syncthreads();
-    for (int e = tid; e < NB * NB; e += 256) {
-      const int i = e / NB, j = e % NB;
-      if (j > k && i >= j && i < nb) L[i][j] -= L[i][k] * L[j][k];
-    }
-    __syncthreads();
-  }
-  if (tid < NB) {
-    const int c = tid;
-    for (int i = 0; i < c; ++i) X[i][c] = 0.0;
-    for (int i = c; i < NB; ++i) {
-      double s = (i == c) ? 1.0 : 0.0;
-      for (int j = c; j < i; ++j) s -= L[i][j] * X[j][c];
-      X[i][c] = s / L[i][i];
-    }
-  }
-  __syncthreads();
-  for (int e = tid; e < NB * NB; e += 256) {
-    const int r = e / NB, c = e % NB;
-    if (r < nb && c <= r) A[(int64_t)r * lda + c] = L[r][c];
-    Linv[e] = X[r][c];
-  }
-}
+// potrf_diag_kernel lives in nk_potrf.hip (fully unrolled, slow to compile)
+int launch_potrf_diag(nk_ctx* ctx, double* Ajj, int64_t lda, int nb, double* Linv, int blk);
 
 int cholesky_lower(nk_ctx* ctx, double* P, int64_t ldp, int m, double* Linv) {
   constexpr int NB = CHOL_NB;
@@ -366,8 +380,7 @@ int cholesky_lower(nk_ctx* ctx, double* P, int64_t ldp, int m, double* Linv) {
     const int nbj = m - j0 < NB ? m - j0 : NB;
     double* Ajj = P + (int64_t)j0 * ldp + j0;
     double* Li = Linv + (size_t)jb * NB * NB;
-    hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(256), 0, ctx->stream, Ajj, ldp, nbj, Li, ctx->d_info, jb);
-    NK_HIP(hipGetLastError());
+    NK_TRY(launch_potrf_diag(ctx, Ajj, ldp, nbj, Li, jb));
     const int rem = m - j0 - nbj;
     if (rem > 0) {
       double* panel = P + (int64_t)(j0 + nbj) * ldp + j0;

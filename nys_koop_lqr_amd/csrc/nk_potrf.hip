@@ -1,0 +1,84 @@
+// Diagonal-block Cholesky of the blocked factorisation (nk_linalg.hip), in its own translation unit because the fully
+// unrolled register-resident kernel takes minutes to compile.  Replaces the LAPACK potrf inside lstsq's role
+// (regressors.py:155,165).
+#include "nk_common.h"
+
+namespace nk {
+
+// ONE WAVE factorises a 64 x 64 diagonal block entirely in registers and inverts the factor.
+//   Factor: lane i owns row i (64 fp64 = 128 VGPRs); right-looking column Cholesky, column k of the other rows is
+//   fetched with v_readlane (no LDS, no barriers): sum_k (63-k) = 2016 readlane pairs + FMAs, fully unrolled.
+//   Inverse: L goes to LDS (stride 65, conflict-free), lane c owns column c of X = L^-1 (forward substitution with
+//   broadcast LDS reads of L).  Blocks shorter than 64 are padded with the identity.
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+
+__global__ void __launch_bounds__(64) potrf_diag_kernel(double* __restrict__ A, int64_t lda, int nb,
+                                                        double* __restrict__ Linv, int* __restrict__ info, int blk) {
+  constexpr int NB = CHOL_NB;
+  static_assert(NB == 64, "one lane per row");
+  __shared__ double Ls[NB * (NB + 1)];
+  __shared__ double dinv[NB];
+  const int lane = threadIdx.x;
+  double R[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    double v = (j == lane) ? 1.0 : 0.0;
+    if (lane < nb && j < nb) v = (j <= lane) ? A[(int64_t)lane * lda + j] : 0.0;
+    R[j] = v;
+  }
+#pragma unroll
+  for (int k = 0; k < NB; ++k) {
+    double dkk = readlane_f64(R[k], k);
+    if (!(dkk > 0.0) || !isfinite(dkk)) {
+      if (lane == 0 && k < nb) atomicCAS(info, 0, blk * NB + k + 1);
+      dkk = 1.0;
+    }
+    const double s = sqrt(dkk);
+    const double inv = 1.0 / s;
+    R[k] = (lane == k) ? s : R[k] * inv;  // lanes > k: L[i][k]; lanes < k hold unused upper-triangle values
+#pragma unroll
+    for (int j = k + 1; j < NB; ++j) {
+      const double ljk = readlane_f64(R[k], j);
+      R[j] = fma(-R[k], ljk, R[j]);
+      if ((j & 7) == 7) __builtin_amdgcn_sched_barrier(0);  // keep the readlane results from piling up in SGPRs
+    }
+  }
+  // L -> LDS and global (lower triangle)
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    Ls[lane * (NB + 1) + j] = (j <= lane) ? R[j] : 0.0;
+    if (lane < nb && j <= lane && j < nb) A[(int64_t)lane * lda + j] = R[j];
+  }
+  __syncthreads();
+  dinv[lane] = 1.0 / Ls[lane * (NB + 1) + lane];
+  __syncthreads();
+  // X = L^-1, column `lane`
+  double X[NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    double s0 = (i == lane) ? 1.0 : 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;  // four chains hide the FMA latency
+#pragma unroll
+    for (int j = 0; j < i; ++j) {
+      const double l = Ls[i * (NB + 1) + j];
+      if ((j & 3) == 0) s0 = fma(-l, X[j], s0);
+      else if ((j & 3) == 1) s1 = fma(-l, X[j], s1);
+      else if ((j & 3) == 2) s2 = fma(-l, X[j], s2);
+      else s3 = fma(-l, X[j], s3);
+    }
+    X[i] = ((s0 + s1) + (s2 + s3)) * dinv[i];
+  }
+#pragma unroll
+  for (int i = 0; i < NB; ++i) Linv[i * NB + lane] = X[i];
+}
+
+int launch_potrf_diag(nk_ctx* ctx, double* Ajj, int64_t lda, int nb, double* Linv, int blk) {
+  hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(64), 0, ctx->stream, Ajj, lda, nb, Linv, ctx->d_info, blk);
+  NK_HIP(hipGetLastError());
+  return NK_OK;
+}
+
+}  // namespace nk
