@@ -171,7 +171,8 @@ def main():
                                                                       "; per-rank CV-grid candidates l in {10,20,40} x gamma in {1e-7..1e-3}"),
                        "n": n, "m": m, "d": d, "p": p, "inputs": "HBM-resident (device pointers through the C-ABI)",
                        "parallelism": "1 process/GPU, independent fits per rank, RCCL all-gather of per-fit scalars"},
-            "stages_ms": {k: avg(k) for k in ("ms_total", "ms_kmat", "ms_gram", "ms_sqrt", "ms_solve")},
+            "stages_ms": {k: avg(k) for k in ("ms_total", "ms_kmat", "ms_gram", "ms_sqrt", "ms_solve", "host_ms_drop",
+                                              "host_ms_call", "host_ms_fetch")},
             "sqrt_iters": int(stats[-1]["sqrt_iters"]),
             "roofline": {"bound": "mfma", "kernel": "nk::gemm_tn_f64_kernel (fused Gram / cross-Gram launch over n)",
                          "achieved": achieved, "peak": MFMA_F64_PEAK_TFLOPS, "unit": "TFLOP/s",

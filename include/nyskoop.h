@@ -78,6 +78,11 @@ int nk_destroy(nk_ctx* ctx);
 int nk_synchronize(nk_ctx* ctx);
 /* the hipStream_t all work of this context is launched on (for event timing by the caller) */
 void* nk_stream(nk_ctx* ctx);
+/* how nk_nystrom_fit builds the two n x m kernel blocks: 0 = automatic (Gram form |a|^2+|b|^2-2ab on the MFMA engine
+ * when d >= 32, direct differences otherwise), 1 = always direct differences like scipy cdist (regressors.py:141-142
+ * -> sklearn -> cdist).  K(Z,Z), lift queries and nk_kernel_matrix always use direct differences.
+ * Also settable with the environment variable NYSKOOP_KMAT=direct before nk_create. */
+int nk_set_kmat_mode(nk_ctx* ctx, int mode);
 
 /* ---- kernel matrix: replaces `kern.kernel(A, B)` (regressors.py:22,26,30 -> sklearn RBF/Matern/DotProduct
  *      __call__): out[i][j] = k(A[i,:], B[j,:]),  A: nA x d, B: nB x d, out: nA x nB. ------------------------ */

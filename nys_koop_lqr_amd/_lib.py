@@ -49,6 +49,7 @@ SIGNATURES = {
     "nk_destroy": (C.c_int, [_P]),
     "nk_synchronize": (C.c_int, [_P]),
     "nk_stream": (_P, [_P]),
+    "nk_set_kmat_mode": (C.c_int, [_P, C.c_int]),
     "nk_kernel_matrix": (C.c_int, [_P, C.POINTER(KernelDesc), _P, _I64, _I64, _P, _I64, _I64, _P, _I64]),
     "nk_nystrom_fit": (C.c_int, [_P, C.POINTER(KernelDesc), _P, _I64, _P, _I64, _I64, _I32, _I32,
                                  C.POINTER(_I64), _I32, _P, _I64, _P, _I64, _I32, _D, _D,
@@ -155,6 +156,10 @@ class Context:
     @property
     def stream(self):
         return self.lib.nk_stream(self.handle)
+
+    def set_kmat_mode(self, mode):
+        """0 = automatic (Gram form on the MFMA engine for d >= 32), 1 = always direct differences."""
+        check(self.lib.nk_set_kmat_mode(self.handle, int(mode)))
 
 
 _contexts = {}

@@ -6,6 +6,10 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <chrono>
+#include <cstdlib>
+#include <algorithm>
+#include <mutex>
 
 namespace nk {
 
@@ -193,6 +197,37 @@ static int make_winv(nk_ctx* ctx, const nk_kernel_desc* kd, int d, double* dst_d
   return NK_OK;
 }
 
+// Model buffers are recycled through a small per-process free list: hipFree synchronises the whole device and a
+// sweep creates and drops one model per fit.
+struct ModelBuf {
+  int device;
+  size_t bytes;
+  double* ptr;
+};
+static std::mutex g_pool_mu;
+static std::vector<ModelBuf> g_pool;
+static double* pool_take(int device, size_t bytes) {
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  for (size_t i = 0; i < g_pool.size(); ++i)
+    if (g_pool[i].device == device && g_pool[i].bytes == bytes) {
+      double* p = g_pool[i].ptr;
+      g_pool.erase(g_pool.begin() + i);
+      return p;
+    }
+  return nullptr;
+}
+static void pool_give(int device, size_t bytes, double* ptr) {
+  {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    if (g_pool.size() < 8) {
+      g_pool.push_back(ModelBuf{device, bytes, ptr});
+      return;
+    }
+  }
+  (void)hipSetDevice(device);
+  (void)hipFree(ptr);
+}
+
 static int model_alloc(nk_ctx* ctx, int m, int d, int p, nk_model** out) {
   nk_model* mdl = new nk_model();
   mdl->device = ctx->device;
@@ -200,12 +235,16 @@ static int model_alloc(nk_ctx* ctx, int m, int d, int p, nk_model** out) {
   const size_t mp = (size_t)m + p;
   const size_t total = (size_t)m * mp /*G=[A B]*/ + (size_t)d * m /*C*/ + (size_t)d * mp /*W*/ + 2 * (size_t)m * m +
                        (size_t)m * d /*Z*/ + (size_t)d /*winv*/ + 64;
-  hipError_t e = hipMalloc(reinterpret_cast<void**>(&mdl->buf), total * sizeof(double));
-  if (e != hipSuccess) {
-    (void)hipGetLastError();
-    delete mdl;
-    set_error("model allocation failed: %s", hipGetErrorString(e));
-    return NK_ERR_OOM;
+  mdl->bytes = total * sizeof(double);
+  mdl->buf = pool_take(ctx->device, mdl->bytes);
+  if (!mdl->buf) {
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&mdl->buf), mdl->bytes);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      delete mdl;
+      set_error("model allocation failed: %s", hipGetErrorString(e));
+      return NK_ERR_OOM;
+    }
   }
   double* q = mdl->buf;
   auto take = [&](size_t cnt) { double* r = q; q += (cnt + 1) & ~(size_t)1; return r; };
@@ -259,6 +298,21 @@ static int predict_device(nk_ctx* ctx, const nk_model* mdl, const double* Xaug, 
   return NK_OK;
 }
 
+// NYSKOOP_TRACE=1: host-side wall clock of the fit's phases on stderr (diagnostics)
+struct HostTrace {
+  bool on;
+  std::chrono::steady_clock::time_point t0, last;
+  HostTrace() : on(getenv("NYSKOOP_TRACE") != nullptr) { t0 = last = std::chrono::steady_clock::now(); }
+  void mark(const char* what) {
+    if (!on) return;
+    auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[nk trace] %-28s +%8.3f ms (total %8.3f)\n", what,
+            std::chrono::duration<double, std::milli>(now - last).count(),
+            std::chrono::duration<double, std::milli>(now - t0).count());
+    last = now;
+  }
+};
+
 static float ev_ms(nk_ctx* ctx, int a, int b) {
   float ms = 0.f;
   (void)hipEventElapsedTime(&ms, ctx->ev[a], ctx->ev[b]);
@@ -308,6 +362,8 @@ int nk_create(int device, nk_ctx** out) {
   NK_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->d_scalars), 64 * sizeof(double)));
   NK_HIP(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_scalars), 64 * sizeof(double)));
   for (int i = 0; i < 16; ++i) NK_HIP(hipEventCreate(&ctx->ev[i]));
+  const char* km = getenv("NYSKOOP_KMAT");
+  ctx->kmat_mode = (km && strcmp(km, "direct") == 0) ? 1 : 0;
   *out = ctx;
   return NK_OK;
 }
@@ -335,6 +391,12 @@ int nk_synchronize(nk_ctx* ctx) {
 
 void* nk_stream(nk_ctx* ctx) { return ctx ? reinterpret_cast<void*>(ctx->stream) : nullptr; }
 
+int nk_set_kmat_mode(nk_ctx* ctx, int mode) {
+  NK_REQUIRE(ctx != nullptr && (mode == 0 || mode == 1), "nk_set_kmat_mode: bad argument");
+  ctx->kmat_mode = mode;
+  return NK_OK;
+}
+
 int nk_kernel_matrix(nk_ctx* ctx, const nk_kernel_desc* kd, const double* A, int64_t lda, int64_t nA, const double* B,
                      int64_t ldb, int64_t nB, double* out, int64_t ldo) {
   NK_TRY(check_ctx(ctx));
@@ -361,7 +423,9 @@ int nk_nystrom_fit(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int64
                    int64_t n, int32_t d, int32_t p, const int64_t* row_ranges, int32_t n_ranges, const double* Zin,
                    int64_t ldzi, const double* Zout, int64_t ldzo, int32_t m, double gamma, double jitter,
                    nk_model** model, nk_fit_stats* stats) {
+  HostTrace tr;
   NK_TRY(check_ctx(ctx));
+  tr.mark("check_ctx/arena_reset");
   NK_REQUIRE(kd && X && Y && Zout && model, "nk_nystrom_fit: null argument");
   NK_REQUIRE(n > 0 && d > 0 && p >= 0 && m > 0, "nk_nystrom_fit: sizes must be positive (n=%lld d=%d p=%d m=%d)",
              (long long)n, d, p, m);
@@ -391,6 +455,7 @@ int nk_nystrom_fit(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int64
   struct Guard { nk_model* m; ~Guard() { if (m) nk_model_destroy(m); } } guard{mdl};
   mdl->ktype = kd->type; mdl->sigma0 = kd->sigma0; mdl->jitter = jitter;
 
+  tr.mark("validate + model_alloc");
   hipEvent_t* ev = ctx->ev;
   NK_HIP(hipEventRecord(ev[0], ctx->stream));
   NK_TRY(make_winv(ctx, kd, d, mdl->winv));
@@ -401,6 +466,7 @@ int nk_nystrom_fit(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int64
   if (same_centers) zi = zo; else NK_TRY(stage_in(ctx, Zin, ldzi, m, d, &zi));
   NK_TRY(launch_copy2d(ctx, zo.ptr, zo.ld, mdl->Z, d, m, d));
   NK_HIP(hipEventRecord(ev[1], ctx->stream));
+  tr.mark("staging issued");
 
   // ---- feature matrix F = [K_nm_in | U | (pad) | K_nm_out], sample-major (regressors.py:141-142,147) ------------
   const int64_t off_out = (mp + 1) & ~1;
@@ -408,14 +474,49 @@ int nk_nystrom_fit(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int64
   double* F = nullptr;
   NK_TRY(arena_alloc_t(ctx, (size_t)n_eff * ldf, &F));
   int64_t o = 0;
-  for (size_t i = 0; i < rng.size(); i += 2) {
-    const int64_t b = rng[i], len = rng[i + 1] - rng[i];
-    NK_TRY(launch_kmat(ctx, kd->type, x.ptr + b * x.ld, x.ld, len, zi.ptr, zi.ld, m, d, mdl->winv, kd->sigma0,
-                       F + o * ldf, ldf));
-    if (p > 0) NK_TRY(launch_copy2d(ctx, x.ptr + b * x.ld + d, x.ld, F + o * ldf + m, ldf, len, p));
-    NK_TRY(launch_kmat(ctx, kd->type, y.ptr + b * y.ld, y.ld, len, zo.ptr, zo.ld, m, d, mdl->winv, kd->sigma0,
-                       F + o * ldf + off_out, ldf));
-    o += len;
+  const bool gram_form = ctx->kmat_mode == 0 && d >= 32;
+  if (gram_form) {
+    // K_nm blocks in Gram form on the MFMA engine: rows centred on the landmark mean, scaled by 1/l, transposed
+    const ArenaMark mk = arena_mark(ctx);
+    int64_t maxlen = 0;
+    for (size_t i = 0; i < rng.size(); i += 2) maxlen = std::max<int64_t>(maxlen, rng[i + 1] - rng[i]);
+    const int64_t ldt = (maxlen + 1) & ~(int64_t)1, ldzt = (m + 1) & ~1;
+    double *center = nullptr, *Rt = nullptr, *sqr = nullptr, *Zto = nullptr, *sqzo = nullptr, *Zti = nullptr, *sqzi = nullptr;
+    NK_TRY(arena_alloc_t(ctx, (size_t)d, &center));
+    NK_TRY(arena_alloc_t(ctx, (size_t)d * ldt, &Rt));
+    NK_TRY(arena_alloc_t(ctx, (size_t)maxlen, &sqr));
+    NK_TRY(arena_alloc_t(ctx, (size_t)d * ldzt, &Zto));
+    NK_TRY(arena_alloc_t(ctx, (size_t)m, &sqzo));
+    NK_TRY(launch_colmean(ctx, zo.ptr, zo.ld, m, d, center));
+    NK_TRY(prep_rows(ctx, zo.ptr, zo.ld, m, d, mdl->winv, center, Zto, ldzt, sqzo));
+    if (same_centers) {
+      Zti = Zto; sqzi = sqzo;
+    } else {
+      NK_TRY(arena_alloc_t(ctx, (size_t)d * ldzt, &Zti));
+      NK_TRY(arena_alloc_t(ctx, (size_t)m, &sqzi));
+      NK_TRY(prep_rows(ctx, zi.ptr, zi.ld, m, d, mdl->winv, center, Zti, ldzt, sqzi));
+    }
+    for (size_t i = 0; i < rng.size(); i += 2) {
+      const int64_t b = rng[i], len = rng[i + 1] - rng[i];
+      NK_TRY(prep_rows(ctx, x.ptr + b * x.ld, x.ld, len, d, mdl->winv, center, Rt, ldt, sqr));
+      NK_TRY(launch_kmat_gram(ctx, kd->type, Rt, ldt, sqr, len, Zti, ldzt, sqzi, m, d, kd->sigma0, F + o * ldf, ldf));
+      if (p > 0) NK_TRY(launch_copy2d(ctx, x.ptr + b * x.ld + d, x.ld, F + o * ldf + m, ldf, len, p));
+      NK_TRY(prep_rows(ctx, y.ptr + b * y.ld, y.ld, len, d, mdl->winv, center, Rt, ldt, sqr));
+      NK_TRY(launch_kmat_gram(ctx, kd->type, Rt, ldt, sqr, len, Zto, ldzt, sqzo, m, d, kd->sigma0, F + o * ldf + off_out,
+                              ldf));
+      o += len;
+    }
+    arena_release(ctx, mk);
+  } else {
+    for (size_t i = 0; i < rng.size(); i += 2) {
+      const int64_t b = rng[i], len = rng[i + 1] - rng[i];
+      NK_TRY(launch_kmat(ctx, kd->type, x.ptr + b * x.ld, x.ld, len, zi.ptr, zi.ld, m, d, mdl->winv, kd->sigma0,
+                         F + o * ldf, ldf));
+      if (p > 0) NK_TRY(launch_copy2d(ctx, x.ptr + b * x.ld + d, x.ld, F + o * ldf + m, ldf, len, p));
+      NK_TRY(launch_kmat(ctx, kd->type, y.ptr + b * y.ld, y.ld, len, zo.ptr, zo.ld, m, d, mdl->winv, kd->sigma0,
+                         F + o * ldf + off_out, ldf));
+      o += len;
+    }
   }
   // ---- landmark kernels (regressors.py:139,143,144) -----------------------------------------------------------------
   double *Kmm = nullptr, *Kj = nullptr, *Kj_in = nullptr, *Kxo = nullptr;
@@ -435,6 +536,7 @@ int nk_nystrom_fit(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int64
     NK_TRY(launch_kmat(ctx, kd->type, zi.ptr, zi.ld, m, zo.ptr, zo.ld, m, d, mdl->winv, kd->sigma0, Kxo, m));
   }
   NK_HIP(hipEventRecord(ev[2], ctx->stream));
+  tr.mark("kmat issued");
 
   // ---- Gram contractions over the samples (regressors.py:151,153,162,164): ONE fused launch ------------------------
   //   G1 = Phi_in^T Phi_in (symmetric), G2t = Phi_in^T Phi_out (= cross^T), G3 = Phi_out^T Phi_out (symmetric),
@@ -495,12 +597,14 @@ int nk_nystrom_fit(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int64
     }
   }
   NK_HIP(hipEventRecord(ev[3], ctx->stream));
+  tr.mark("gram issued (+sync if timed)");
 
   // ---- S = K_mm^{1/2}, S^{-1} (regressors.py:140,163) ------------------------------------------------------------------
   int it = 0;
   double resid = 0.0;
   NK_TRY(sqrtm_spd(ctx, Kj, m, m, mdl->S, mdl->Sinv, &it, &resid));
   NK_HIP(hipEventRecord(ev[4], ctx->stream));
+  tr.mark("sqrt done (host-synced)");
 
   // ---- [A B] = S^-1 (Phi_out Phi_in^T) inner^-1 blkdiag(K_xo S^-1, I)   (regressors.py:151-159) ------------------------
   // all products are written as P^T Q with P stored contraction-major (the fast TN engine); explicit transposes
@@ -523,23 +627,30 @@ int nk_nystrom_fit(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int64
   NK_TRY(launch_fill(ctx, right, mp, mp, mp, 0.0));
   NK_TRY(launch_gemm(ctx, true, false, m, m, m, 1.0, Kxot, m, mdl->Sinv, m, 0.0, right, mp));    // K_xo S^-1
   if (p > 0) NK_TRY(launch_add_diag(ctx, right + (int64_t)m * mp + m, mp, p, 1.0));
-  NK_TRY(cholesky_lower(ctx, G1, mp, mp, Linv));
-  NK_TRY(cholesky_solve(ctx, G1, mp, mp, Linv, right, mp, mp));                                   // sol
-  NK_TRY(launch_gemm(ctx, true, false, m, mp, mp, 1.0, G2t, m, right, mp, 0.0, T2, mp));          // cross * sol
-  NK_TRY(launch_gemm(ctx, true, false, m, mp, m, 1.0, Sinvt, m, T2, mp, 0.0, mdl->A, mp));        // G = S^-1 (.)
-  // ---- C = (Y Phi_out^T) (gamma_n K + Phi_out Phi_out^T)^-1 S   (regressors.py:162-166) ---------------------------------
+  // inner_rec = gamma_n K + Phi_out Phi_out^T and its right-hand side S   (regressors.py:162-163)
   NK_TRY(launch_axpby2d(ctx, gamma_n, Kj, m, 1.0, G3, m, m, m));
-  double *sol_rec = nullptr, *Ct = nullptr;
+  double *sol_rec = nullptr, *Ct = nullptr, *Linv2 = nullptr;
   NK_TRY(arena_alloc_t(ctx, (size_t)m * m, &sol_rec));
   NK_TRY(arena_alloc_t(ctx, (size_t)m * ldd, &Ct));
+  NK_TRY(arena_alloc_t(ctx, (size_t)nblk * CHOL_NB * CHOL_NB, &Linv2));
   NK_TRY(launch_copy2d(ctx, mdl->S, m, sol_rec, m, m, m));
-  NK_TRY(cholesky_lower(ctx, G3, m, m, Linv));
-  NK_TRY(cholesky_solve(ctx, G3, m, m, Linv, sol_rec, m, m));
+  // both regularised systems are factorised and solved in lock step (paired launches): the per-block kernels are
+  // latency bound, pairing halves the chain
+  CholSys sys[2];
+  sys[0].P = G1; sys[0].ldp = mp; sys[0].m = mp; sys[0].Linv = Linv; sys[0].R = right; sys[0].ldr = mp; sys[0].nrhs = mp;
+  sys[1].P = G3; sys[1].ldp = m; sys[1].m = m; sys[1].Linv = Linv2; sys[1].R = sol_rec; sys[1].ldr = m; sys[1].nrhs = m;
+  NK_TRY(cholesky_lower_pair(ctx, sys, 2));
+  NK_TRY(cholesky_solve_pair(ctx, sys, 2));                                                       // sol, sol_rec
+  NK_TRY(launch_gemm(ctx, true, false, m, mp, mp, 1.0, G2t, m, right, mp, 0.0, T2, mp));          // cross * sol
+  NK_TRY(launch_gemm(ctx, true, false, m, mp, m, 1.0, Sinvt, m, T2, mp, 0.0, mdl->A, mp));        // G = S^-1 (.)
+  // ---- C = (Y Phi_out^T) inner_rec^-1 S   (regressors.py:164-166) -------------------------------------------------------
   NK_TRY(launch_gemm(ctx, true, false, d, m, m, 1.0, G4t, ldd, sol_rec, m, 0.0, mdl->C, m));      // C = left_rec sol_rec
   NK_TRY(launch_transpose(ctx, mdl->C, m, Ct, ldd, d, m));
   NK_TRY(launch_gemm(ctx, true, false, d, mp, m, 1.0, Ct, ldd, mdl->A, mp, 0.0, mdl->W, mp));     // W = C G (:167)
   NK_HIP(hipEventRecord(ev[5], ctx->stream));
+  tr.mark("solve issued");
   NK_HIP(hipStreamSynchronize(ctx->stream));
+  tr.mark("final sync");
   mdl->has_ops = true;
 
   if (stats) {
@@ -616,8 +727,7 @@ int nk_model_create(nk_ctx* ctx, const nk_kernel_desc* kd, const double* Zout, i
 
 int nk_model_destroy(nk_model* model) {
   if (!model) return NK_OK;
-  (void)hipSetDevice(model->device);
-  (void)hipFree(model->buf);
+  pool_give(model->device, model->bytes, model->buf);
   delete model;
   return NK_OK;
 }

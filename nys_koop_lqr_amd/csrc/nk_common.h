@@ -58,12 +58,13 @@ struct nk_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   nk::Arena arena;
-  int* d_info = nullptr;       // device flag for factorisation failures
+  int* d_info = nullptr;       // device flags for factorisation failures (one int per paired system)
   double* d_scalars = nullptr; // small device scratch for reductions (64 doubles)
   double* h_scalars = nullptr; // pinned host mirror
   double* d_zeros = nullptr;   // 4 KiB zero page (K-tail rows of the LDS-DMA GEMM)
   hipEvent_t ev[16];
   int num_cu = 256;
+  int kmat_mode = 0;  // 0 auto (Gram form on MFMA for d >= 32), 1 always direct differences (NYSKOOP_KMAT=direct)
 };
 
 struct nk_model {
@@ -73,6 +74,7 @@ struct nk_model {
   double sigma0 = 0.0;
   double jitter = 0.0;
   double* buf = nullptr;  // one allocation holding everything below
+  size_t bytes = 0;
   double *A = nullptr, *B = nullptr, *C = nullptr, *W = nullptr, *S = nullptr, *Sinv = nullptr, *Z = nullptr,
          *winv = nullptr;  // winv: 1/lengthscale per dimension (d entries)
   bool has_ops = false;
@@ -106,6 +108,18 @@ int launch_gemm(nk_ctx* ctx, bool transA, bool transB, int64_t M, int64_t N, int
                 int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc,
                 const GemmOpts& opts = GemmOpts(), float* ms_kernel = nullptr);
 
+struct GemmCall {
+  int64_t M = 0, N = 0, K = 0;
+  double alpha = 1.0, beta = 0.0;
+  const double* A = nullptr;
+  const double* B = nullptr;
+  double* C = nullptr;
+  int64_t lda = 0, ldb = 0, ldc = 0;
+  GemmOpts opts;
+};
+// up to two independent problems with the same transposition flags in one launch (no split-K)
+int launch_gemm_pair(nk_ctx* ctx, bool transA, bool transB, const GemmCall* calls, int ncalls);
+
 // elementwise / reductions
 int launch_add_diag(nk_ctx* ctx, double* A, int64_t lda, int n, double v);
 int launch_copy2d(nk_ctx* ctx, const double* src, int64_t lds, double* dst, int64_t ldd, int64_t rows, int64_t cols);
@@ -126,6 +140,19 @@ int sqrtm_spd(nk_ctx* ctx, const double* P, int64_t ldp, int m, double* S, doubl
 int cholesky_lower(nk_ctx* ctx, double* P, int64_t ldp, int m, double* Linv /* nblk*NB*NB */);
 int cholesky_solve(nk_ctx* ctx, const double* L, int64_t ldl, int m, const double* Linv, double* R, int64_t ldr,
                    int nrhs);  // R <- (L L^T)^{-1} R in place
+// the same for TWO independent systems advanced in lock step, every per-block kernel launched once for both
+// (the chains are latency bound: pairing halves their length)
+struct CholSys {
+  double* P = nullptr;   // matrix, overwritten by its lower factor
+  int64_t ldp = 0;
+  int m = 0;
+  double* Linv = nullptr;
+  double* R = nullptr;   // right-hand sides (solve only), overwritten by the solution
+  int64_t ldr = 0;
+  int nrhs = 0;
+};
+int cholesky_lower_pair(nk_ctx* ctx, const CholSys* sys, int nsys);
+int cholesky_solve_pair(nk_ctx* ctx, const CholSys* sys, int nsys);
 constexpr int CHOL_NB = 64;
 
 }  // namespace nk
@@ -147,4 +174,12 @@ bool tn_fast_ok(const TnProblem& p);  // alignment / leading-dimension requireme
 int launch_gemm_tn_multi(nk_ctx* ctx, const TnProblem* probs, int nprob, int64_t K, int splitk /*0=auto*/,
                          float* ms_kernel = nullptr);
 int launch_transpose(nk_ctx* ctx, const double* src, int64_t lds, double* dst, int64_t ldd, int rows, int cols);
+// Gram-form kernel matrix on the MFMA engine (nk_gemm_tn.hip): prep_rows centres/scales/transposes rows to
+// contraction-major and returns their squared norms; launch_kmat_gram evaluates k() in the GEMM epilogue
+int launch_colmean(nk_ctx* ctx, const double* Z, int64_t ldz, int rows, int d, double* mean);
+int prep_rows(nk_ctx* ctx, const double* X, int64_t ldx, int64_t rows, int d, const double* winv, const double* center,
+              double* Xt, int64_t ldt, double* sq);
+int launch_kmat_gram(nk_ctx* ctx, int ktype, const double* At, int64_t ldat, const double* sqa, int64_t nA,
+                     const double* Bt, int64_t ldbt, const double* sqb, int64_t nB, int d, double sigma0, double* out,
+                     int64_t ldo);
 }  // namespace nk

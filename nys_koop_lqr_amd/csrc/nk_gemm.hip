@@ -43,6 +43,11 @@ struct GemmParams {
   int klen;  // K elements per split (multiple of BK)
   int vecA, vecB;
   double alpha, beta;
+  int nblocks;  // tiles * splitk of this problem
+};
+constexpr int GEMM_MAX_BATCH = 2;
+struct GemmBatch {
+  GemmParams p[GEMM_MAX_BATCH];
 };
 
 __device__ __forceinline__ void tile_from_index(int t, int tiles_m, int tiles_n, int tri, int& tm, int& tn) {
@@ -133,8 +138,10 @@ __device__ __forceinline__ void store_transposing(double* __restrict__ S, const 
 }
 
 template <bool TA, bool TB>
-__global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_f64_kernel(GemmParams p) {
+__global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_f64_kernel(GemmBatch batch) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
+  const GemmParams& p = batch.p[blockIdx.y];  // blockIdx.y selects the problem of a batched launch
+  if ((int)blockIdx.x >= p.nblocks) return;
   double* As = smem;                          // [2][BK][LDS_STRIDE]
   double* Bs = smem + 2 * BK * LDS_STRIDE;    // [2][BK][LDS_STRIDE]
 
@@ -257,19 +264,12 @@ __global__ void __launch_bounds__(256) gemm_reduce_kernel(const double* __restri
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-int launch_gemm(nk_ctx* ctx, bool transA, bool transB, int64_t M, int64_t N, int64_t K, double alpha, const double* A,
-                int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc, const GemmOpts& opts,
-                float* ms_kernel) {
-  if (M <= 0 || N <= 0) return NK_OK;
+// Fill the device parameters of one problem (no split-K slab handling: splitk must resolve to 1 for batched use).
+static int gemm_prepare(nk_ctx* ctx, bool transA, bool transB, int64_t M, int64_t N, int64_t K, double alpha,
+                        const double* A, int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc,
+                        const GemmOpts& opts, GemmParams* out, int* ntiles_out) {
   NK_REQUIRE(M < (1 << 30) && N < (1 << 30) && K < (1LL << 31) && K >= 0, "nk_gemm: dimension out of range");
-  if (transA && !transB && opts.tri != TRI_LOWER && opts.splitk == 0 && K >= 128) {
-    // contraction-major operands: LDS-DMA engine (nk_gemm_tn.hip) when the alignment contract holds
-    TnProblem tp;
-    tp.A = A; tp.B = B; tp.C = C; tp.lda = lda; tp.ldb = ldb; tp.ldc = ldc; tp.M = (int)M; tp.N = (int)N;
-    tp.tri = opts.tri; tp.alpha = alpha; tp.beta = beta;
-    if (tn_fast_ok(tp) && (opts.tri == TRI_FULL || M == N)) return launch_gemm_tn_multi(ctx, &tp, 1, K, 0, ms_kernel);
-  }
-  GemmParams p;
+  GemmParams& p = *out;
   p.A = A; p.B = B; p.C = C; p.slab = nullptr;
   p.lda = lda; p.ldb = ldb; p.ldc = ldc;
   p.M = (int)M; p.N = (int)N; p.K = (int)K;
@@ -280,7 +280,7 @@ int launch_gemm(nk_ctx* ctx, bool transA, bool transB, int64_t M, int64_t N, int
   p.alpha = alpha; p.beta = beta;
   p.vecA = aligned16(A) && (lda % 2 == 0);
   p.vecB = aligned16(B) && (ldb % 2 == 0);
-  int ntiles = p.tri == TRI_FULL ? p.tiles_m * p.tiles_n : p.tiles_m * (p.tiles_m + 1) / 2;
+  const int ntiles = p.tri == TRI_FULL ? p.tiles_m * p.tiles_n : p.tiles_m * (p.tiles_m + 1) / 2;
   const int ktiles_total = (int)((K + BK - 1) / BK);
   int splitk = opts.splitk;
   if (splitk <= 0) {
@@ -295,13 +295,12 @@ int launch_gemm(nk_ctx* ctx, bool transA, bool transB, int64_t M, int64_t N, int
   p.splitk = splitk;
   p.klen = ((ktiles_total + splitk - 1) / splitk) * BK;
   if (p.klen == 0) p.klen = BK;
+  p.nblocks = ntiles * splitk;
+  *ntiles_out = ntiles;
+  return NK_OK;
+}
 
-  const ArenaMark mark = arena_mark(ctx);
-  if (splitk > 1) {
-    double* slab = nullptr;
-    NK_TRY(arena_alloc_t(ctx, (size_t)splitk * M * N, &slab));
-    p.slab = slab;
-  }
+static int gemm_set_attrs() {
   static bool attr_set = false;
   if (!attr_set) {
     NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f64_kernel<false, false>),
@@ -314,12 +313,71 @@ int launch_gemm(nk_ctx* ctx, bool transA, bool transB, int64_t M, int64_t N, int
                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     attr_set = true;
   }
-  dim3 grid((unsigned)(ntiles * splitk)), block(GEMM_THREADS);
+  return NK_OK;
+}
+
+static void gemm_dispatch(nk_ctx* ctx, bool transA, bool transB, dim3 grid, const GemmBatch& b) {
+  dim3 block(GEMM_THREADS);
+  if (transA && transB) hipLaunchKernelGGL((gemm_f64_kernel<true, true>), grid, block, LDS_BYTES, ctx->stream, b);
+  else if (transA) hipLaunchKernelGGL((gemm_f64_kernel<true, false>), grid, block, LDS_BYTES, ctx->stream, b);
+  else if (transB) hipLaunchKernelGGL((gemm_f64_kernel<false, true>), grid, block, LDS_BYTES, ctx->stream, b);
+  else hipLaunchKernelGGL((gemm_f64_kernel<false, false>), grid, block, LDS_BYTES, ctx->stream, b);
+}
+
+// Two independent small problems with the same transposition flags in ONE launch (blockIdx.y = problem).  Used by the
+// paired Cholesky factorisations / triangular solves of the fit, whose per-step kernels are latency bound.
+int launch_gemm_pair(nk_ctx* ctx, bool transA, bool transB, const GemmCall* calls, int ncalls) {
+  NK_REQUIRE(ncalls >= 1 && ncalls <= GEMM_MAX_BATCH, "gemm_pair: 1..2 problems");
+  GemmBatch b;
+  int maxblocks = 0, live = 0;
+  for (int q = 0; q < GEMM_MAX_BATCH; ++q) {
+    if (q < ncalls && calls[q].M > 0 && calls[q].N > 0) {
+      GemmOpts o = calls[q].opts;
+      o.splitk = 1;
+      int nt = 0;
+      NK_TRY(gemm_prepare(ctx, transA, transB, calls[q].M, calls[q].N, calls[q].K, calls[q].alpha, calls[q].A,
+                          calls[q].lda, calls[q].B, calls[q].ldb, calls[q].beta, calls[q].C, calls[q].ldc, o, &b.p[q], &nt));
+      if (b.p[q].nblocks > maxblocks) maxblocks = b.p[q].nblocks;
+      ++live;
+    } else {
+      b.p[q] = GemmParams{};
+      b.p[q].nblocks = 0;
+    }
+  }
+  if (live == 0) return NK_OK;
+  NK_TRY(gemm_set_attrs());
+  gemm_dispatch(ctx, transA, transB, dim3((unsigned)maxblocks, (unsigned)GEMM_MAX_BATCH), b);
+  NK_HIP(hipGetLastError());
+  return NK_OK;
+}
+
+int launch_gemm(nk_ctx* ctx, bool transA, bool transB, int64_t M, int64_t N, int64_t K, double alpha, const double* A,
+                int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc, const GemmOpts& opts,
+                float* ms_kernel) {
+  if (M <= 0 || N <= 0) return NK_OK;
+  if (transA && !transB && opts.tri != TRI_LOWER && opts.splitk == 0 && K >= 128) {
+    // contraction-major operands: LDS-DMA engine (nk_gemm_tn.hip) when the alignment contract holds
+    TnProblem tp;
+    tp.A = A; tp.B = B; tp.C = C; tp.lda = lda; tp.ldb = ldb; tp.ldc = ldc; tp.M = (int)M; tp.N = (int)N;
+    tp.tri = opts.tri; tp.alpha = alpha; tp.beta = beta;
+    if (tn_fast_ok(tp) && (opts.tri == TRI_FULL || M == N)) return launch_gemm_tn_multi(ctx, &tp, 1, K, 0, ms_kernel);
+  }
+  GemmBatch b;
+  b.p[1] = GemmParams{};
+  b.p[1].nblocks = 0;
+  int ntiles = 0;
+  NK_TRY(gemm_prepare(ctx, transA, transB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, opts, &b.p[0], &ntiles));
+  GemmParams& p = b.p[0];
+  const int splitk = p.splitk;
+  const ArenaMark mark = arena_mark(ctx);
+  if (splitk > 1) {
+    double* slab = nullptr;
+    NK_TRY(arena_alloc_t(ctx, (size_t)splitk * M * N, &slab));
+    p.slab = slab;
+  }
+  NK_TRY(gemm_set_attrs());
   if (ms_kernel) NK_HIP(hipEventRecord(ctx->ev[14], ctx->stream));
-  if (transA && transB) hipLaunchKernelGGL((gemm_f64_kernel<true, true>), grid, block, LDS_BYTES, ctx->stream, p);
-  else if (transA) hipLaunchKernelGGL((gemm_f64_kernel<true, false>), grid, block, LDS_BYTES, ctx->stream, p);
-  else if (transB) hipLaunchKernelGGL((gemm_f64_kernel<false, true>), grid, block, LDS_BYTES, ctx->stream, p);
-  else hipLaunchKernelGGL((gemm_f64_kernel<false, false>), grid, block, LDS_BYTES, ctx->stream, p);
+  gemm_dispatch(ctx, transA, transB, dim3((unsigned)p.nblocks, 1), b);
   NK_HIP(hipGetLastError());
   if (ms_kernel) {
     NK_HIP(hipEventRecord(ctx->ev[15], ctx->stream));

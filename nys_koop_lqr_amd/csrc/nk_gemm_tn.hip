@@ -42,6 +42,13 @@ struct TnParams {
   int K, splitk, klen;
   const double* zeros;  // >= 1 KiB of zeros
   double* slab;
+  // fused kernel-matrix epilogue (EPI == 1): out[i][j] = k(sqa[i] + sqb[j] - 2 acc)
+  const double* sqa;
+  const double* sqb;
+  double* out;
+  int64_t ldo;
+  int ktype;
+  double sigma0sq;
 };
 
 __device__ __forceinline__ void dma_row(const double* gsrc, double* lds_row) {
@@ -49,6 +56,7 @@ __device__ __forceinline__ void dma_row(const double* gsrc, double* lds_row) {
                                    (__attribute__((address_space(3))) void*)lds_row, 16, 0, 0);
 }
 
+template <int EPI>
 __global__ void __launch_bounds__(256, 2) gemm_tn_f64_kernel(TnParams P) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int split = blockIdx.x % P.splitk;
@@ -135,18 +143,56 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_f64_kernel(TnParams P) {
     }
   }
 
-  // raw 128x128 partial tile -> slab[(tile*splitk + split)]
-  double* out = P.slab + ((int64_t)gt * P.splitk + split) * (TBM * TBM);
+  if (EPI == 0) {
+    // raw 128x128 partial tile -> slab[(tile*splitk + split)]
+    double* out = P.slab + ((int64_t)gt * P.splitk + split) * (TBM * TBM);
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int row = wm * 64 + i * 16 + g4 + 4 * reg;
+          const int col = wn * 64 + j * 16 + r16;
+          out[row * TBM + col] = acc[i][j][reg];
+        }
+  } else {
+    // kernel-matrix epilogue: squared distance from the Gram form, then the kernel function
+    double sb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int col = tn * TBM + wn * 64 + j * 16 + r16;
+      sb[j] = col < pr.N ? P.sqb[col] : 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
-        const int row = wm * 64 + i * 16 + g4 + 4 * reg;
-        const int col = wn * 64 + j * 16 + r16;
-        out[row * TBM + col] = acc[i][j][reg];
+        const int row = tm * TBM + wm * 64 + i * 16 + g4 + 4 * reg;
+        if (row >= pr.M) continue;
+        const double sa = P.sqa[row];
+        double* orow = P.out + (int64_t)row * P.ldo;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int col = tn * TBM + wn * 64 + j * 16 + r16;
+          if (col >= pr.N) continue;
+          const double dot = acc[i][j][reg];
+          double v;
+          if (P.ktype == NK_KERNEL_LINEAR) {
+            v = dot + P.sigma0sq;
+          } else {
+            const double D = fmax(sa + sb[j] - 2.0 * dot, 0.0);
+            if (P.ktype == NK_KERNEL_RBF) {
+              v = exp(-0.5 * D);
+            } else {
+              const double t = sqrt(D) * 2.23606797749978969641;
+              v = (1.0 + t + t * t / 3.0) * exp(-t);
+            }
+          }
+          orow[col] = v;
+        }
       }
+  }
 }
 
 struct TnRed {
@@ -232,6 +278,8 @@ bool tn_fast_ok(const TnProblem& p) {
          p.lda >= ((p.M + 1) & ~1) && p.ldb >= ((p.N + 1) & ~1);
 }
 
+static bool g_tn_attr_set = false;
+
 static int ensure_zero_page(nk_ctx* ctx) {
   if (ctx->d_zeros) return NK_OK;
   NK_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->d_zeros), 4096));
@@ -298,14 +346,16 @@ int launch_gemm_tn_multi(nk_ctx* ctx, const TnProblem* probs, int nprob, int64_t
   NK_TRY(arena_alloc_t(ctx, (size_t)ntiles * splitk * TBM * TBM, &slab));
   P.slab = slab;
   R.nprob = nprob; R.splitk = splitk; R.slab = slab;
-  static bool attr_set = false;
-  if (!attr_set) {
-    NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_f64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               TN_LDS_BYTES));
-    attr_set = true;
+  if (!g_tn_attr_set) {
+    NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_f64_kernel<0>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES));
+    NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_f64_kernel<1>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES));
+    g_tn_attr_set = true;
   }
   if (ms_kernel) NK_HIP(hipEventRecord(ctx->ev[14], ctx->stream));
-  hipLaunchKernelGGL(gemm_tn_f64_kernel, dim3((unsigned)(ntiles * splitk)), dim3(256), TN_LDS_BYTES, ctx->stream, P);
+  P.sqa = P.sqb = nullptr; P.out = nullptr; P.ldo = 0; P.ktype = 0; P.sigma0sq = 0.0;
+  hipLaunchKernelGGL(gemm_tn_f64_kernel<0>, dim3((unsigned)(ntiles * splitk)), dim3(256), TN_LDS_BYTES, ctx->stream, P);
   NK_HIP(hipGetLastError());
   if (ms_kernel) NK_HIP(hipEventRecord(ctx->ev[15], ctx->stream));
   hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, R);
@@ -315,6 +365,113 @@ int launch_gemm_tn_multi(nk_ctx* ctx, const TnProblem* probs, int nprob, int64_t
     NK_HIP(hipEventElapsedTime(ms_kernel, ctx->ev[14], ctx->ev[15]));
   }
   arena_release(ctx, mark);
+  return NK_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// Kernel matrix in Gram form on the MFMA engine (large d): out[i][j] = k(|a_i|^2 + |b_j|^2 - 2 a_i.b_j) with the rows
+// centred, scaled by 1/lengthscale and transposed to contraction-major first.  Used for the two n x m blocks of the
+// fit when d >= 32; K(Z, Z), small d and nk_kernel_matrix keep the direct-difference kernel (nk_kmat.hip).
+// Error of the Gram form: |dD| <~ eps * (|a|^2 + |b|^2) absolute, i.e. a RELATIVE error of |dD|/2 on k (RBF), which the
+// centring keeps at the 1e-15 level for the shapes of SURVEY 8d.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) prep_rows_kernel(const double* __restrict__ X, int64_t ldx, int rows, int d,
+                                                        const double* __restrict__ winv, const double* __restrict__ center,
+                                                        double* __restrict__ Xt, int64_t ldt) {
+  __shared__ double tile[32][33];
+  const int k0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int r = ty; r < 32; r += 8) {
+    const int row = r0 + r, k = k0 + tx;
+    if (row < rows && k < d) tile[r][tx] = (X[(int64_t)row * ldx + k] - center[k]) * winv[k];
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int k = k0 + r, row = r0 + tx;
+    if (k < d && row < rows) Xt[(int64_t)k * ldt + row] = tile[tx][r];
+  }
+}
+__global__ void __launch_bounds__(256) colsq_kernel(const double* __restrict__ Xt, int64_t ldt, int rows, int d,
+                                                    double* __restrict__ sq) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows) return;
+  double s = 0.0;
+  for (int k = 0; k < d; ++k) {
+    const double v = Xt[(int64_t)k * ldt + i];
+    s = fma(v, v, s);
+  }
+  sq[i] = s;
+}
+// column means in two deterministic passes: per-chunk partial sums (coalesced across columns), then a fixed-order sum
+__global__ void __launch_bounds__(256) colsum_partial_kernel(const double* __restrict__ Z, int64_t ldz, int rows, int d,
+                                                             int rows_per_chunk, double* __restrict__ partial) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= d) return;
+  const int r0 = blockIdx.y * rows_per_chunk;
+  const int r1 = min(rows, r0 + rows_per_chunk);
+  double s = 0.0;
+  for (int r = r0; r < r1; ++r) s += Z[(int64_t)r * ldz + k];
+  partial[(int64_t)blockIdx.y * d + k] = s;
+}
+__global__ void __launch_bounds__(256) colmean_finish_kernel(const double* __restrict__ partial, int chunks, int rows, int d,
+                                                             double* __restrict__ mean) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= d) return;
+  double s = 0.0;
+  for (int c = 0; c < chunks; ++c) s += partial[(int64_t)c * d + k];
+  mean[k] = s / rows;
+}
+
+int launch_colmean(nk_ctx* ctx, const double* Z, int64_t ldz, int rows, int d, double* mean) {
+  const ArenaMark mk = arena_mark(ctx);
+  const int rpc = 32;
+  const int chunks = (rows + rpc - 1) / rpc;
+  double* partial = nullptr;
+  NK_TRY(arena_alloc_t(ctx, (size_t)chunks * d, &partial));
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3((d + 255) / 256, chunks), dim3(256), 0, ctx->stream, Z, ldz, rows, d, rpc,
+                     partial);
+  hipLaunchKernelGGL(colmean_finish_kernel, dim3((d + 255) / 256), dim3(256), 0, ctx->stream, partial, chunks, rows, d, mean);
+  NK_HIP(hipGetLastError());
+  arena_release(ctx, mk);
+  return NK_OK;
+}
+
+int prep_rows(nk_ctx* ctx, const double* X, int64_t ldx, int64_t rows, int d, const double* winv, const double* center,
+              double* Xt, int64_t ldt, double* sq) {
+  dim3 grid((d + 31) / 32, (unsigned)((rows + 31) / 32));
+  hipLaunchKernelGGL(prep_rows_kernel, grid, dim3(256), 0, ctx->stream, X, ldx, (int)rows, d, winv, center, Xt, ldt);
+  hipLaunchKernelGGL(colsq_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, ctx->stream, Xt, ldt, (int)rows, d, sq);
+  NK_HIP(hipGetLastError());
+  return NK_OK;
+}
+
+int launch_kmat_gram(nk_ctx* ctx, int ktype, const double* At, int64_t ldat, const double* sqa, int64_t nA,
+                     const double* Bt, int64_t ldbt, const double* sqb, int64_t nB, int d, double sigma0, double* out,
+                     int64_t ldo) {
+  NK_TRY(ensure_zero_page(ctx));
+  TnProblem tp;
+  tp.A = At; tp.B = Bt; tp.lda = ldat; tp.ldb = ldbt; tp.M = (int)nA; tp.N = (int)nB;
+  NK_REQUIRE(tn_fast_ok(tp), "kmat_gram: operands violate the alignment contract");
+  TnParams P;
+  const int tmn = (int)((nA + TBM - 1) / TBM), tnn = (int)((nB + TBM - 1) / TBM);
+  TnDev& dv = P.p[0];
+  dv.A = At; dv.B = Bt; dv.lda = ldat; dv.ldb = ldbt; dv.M = (int)nA; dv.N = (int)nB; dv.tiles_n = tnn; dv.tri = TRI_FULL;
+  dv.tile_begin = 0;
+  for (int q = 1; q < TN_MAXP; ++q) { P.p[q] = P.p[0]; P.p[q].tile_begin = 1 << 30; }
+  P.nprob = 1; P.ntiles = tmn * tnn; P.K = d; P.splitk = 1;
+  P.klen = ((d + TBK - 1) / TBK) * TBK;
+  P.zeros = ctx->d_zeros; P.slab = nullptr;
+  P.sqa = sqa; P.sqb = sqb; P.out = out; P.ldo = ldo; P.ktype = ktype; P.sigma0sq = sigma0 * sigma0;
+  if (!g_tn_attr_set) {
+    NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_f64_kernel<0>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES));
+    NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_f64_kernel<1>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES));
+    g_tn_attr_set = true;
+  }
+  hipLaunchKernelGGL(gemm_tn_f64_kernel<1>, dim3((unsigned)P.ntiles), dim3(256), TN_LDS_BYTES, ctx->stream, P);
+  NK_HIP(hipGetLastError());
   return NK_OK;
 }
 

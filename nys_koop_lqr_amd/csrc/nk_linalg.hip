@@ -6,6 +6,7 @@
 //     there is no silent rank truncation.
 #include "nk_common.h"
 
+#include <algorithm>
 #include <cmath>
 
 namespace nk {
@@ -364,74 +365,122 @@ int sqrtm_spd(nk_ctx* ctx, const double* P, int64_t ldp, int m, double* S, doubl
 // blocked Cholesky (lower) with inverted diagonal blocks
 // ---------------------------------------------------------------------------------------------------------------
 // potrf_diag_kernel lives in nk_potrf.hip (fully unrolled, slow to compile)
-int launch_potrf_diag(nk_ctx* ctx, double* Ajj, int64_t lda, int nb, double* Linv, int blk);
+int launch_potrf_diag_pair(nk_ctx* ctx, double* const* Ajj, const int64_t* lda, const int* nb, double* const* Linv,
+                           int nsys, int blk);
 
-int cholesky_lower(nk_ctx* ctx, double* P, int64_t ldp, int m, double* Linv) {
+int cholesky_lower_pair(nk_ctx* ctx, const CholSys* sys, int nsys) {
   constexpr int NB = CHOL_NB;
-  NK_HIP(hipMemsetAsync(ctx->d_info, 0, sizeof(int), ctx->stream));
-  const int nblk = (m + NB - 1) / NB;
-  GemmOpts lower;
-  lower.tri = TRI_LOWER;
-  lower.splitk = 1;
-  GemmOpts one;
-  one.splitk = 1;
+  NK_REQUIRE(nsys >= 1 && nsys <= 2, "cholesky_lower_pair: 1..2 systems");
+  NK_HIP(hipMemsetAsync(ctx->d_info, 0, 2 * sizeof(int), ctx->stream));
+  int nblk = 0;
+  for (int q = 0; q < nsys; ++q) nblk = std::max(nblk, (sys[q].m + NB - 1) / NB);
   for (int jb = 0; jb < nblk; ++jb) {
     const int j0 = jb * NB;
-    const int nbj = m - j0 < NB ? m - j0 : NB;
-    double* Ajj = P + (int64_t)j0 * ldp + j0;
-    double* Li = Linv + (size_t)jb * NB * NB;
-    NK_TRY(launch_potrf_diag(ctx, Ajj, ldp, nbj, Li, jb));
-    const int rem = m - j0 - nbj;
-    if (rem > 0) {
-      double* panel = P + (int64_t)(j0 + nbj) * ldp + j0;
-      // panel <- panel * Linv_jj^T   (in place: one n-tile, every workgroup reads exactly the rows it writes)
-      NK_TRY(launch_gemm(ctx, false, true, rem, nbj, nbj, 1.0, panel, ldp, Li, NB, 0.0, panel, ldp, one));
-      // trailing <- trailing - panel * panel^T  (lower tiles)
-      double* trail = P + (int64_t)(j0 + nbj) * ldp + (j0 + nbj);
-      NK_TRY(launch_gemm(ctx, false, true, rem, rem, nbj, -1.0, panel, ldp, panel, ldp, 1.0, trail, ldp, lower));
+    double* Ajj[2] = {nullptr, nullptr};
+    double* Li[2] = {nullptr, nullptr};
+    int64_t lda[2] = {0, 0};
+    int nbj[2] = {0, 0};
+    GemmCall panel[2], trail[2];
+    for (int q = 0; q < nsys; ++q) {
+      const CholSys& y = sys[q];
+      if (j0 >= y.m) continue;
+      nbj[q] = y.m - j0 < NB ? y.m - j0 : NB;
+      Ajj[q] = y.P + (int64_t)j0 * y.ldp + j0;
+      lda[q] = y.ldp;
+      Li[q] = y.Linv + (size_t)jb * NB * NB;
+      const int rem = y.m - j0 - nbj[q];
+      if (rem > 0) {
+        double* pnl = y.P + (int64_t)(j0 + nbj[q]) * y.ldp + j0;
+        // panel <- panel * Linv_jj^T   (in place: one n-tile, every workgroup reads exactly the rows it writes)
+        panel[q].M = rem; panel[q].N = nbj[q]; panel[q].K = nbj[q];
+        panel[q].A = pnl; panel[q].lda = y.ldp; panel[q].B = Li[q]; panel[q].ldb = NB;
+        panel[q].C = pnl; panel[q].ldc = y.ldp;
+        // trailing <- trailing - panel * panel^T  (lower tiles)
+        trail[q].M = rem; trail[q].N = rem; trail[q].K = nbj[q]; trail[q].alpha = -1.0; trail[q].beta = 1.0;
+        trail[q].A = pnl; trail[q].lda = y.ldp; trail[q].B = pnl; trail[q].ldb = y.ldp;
+        trail[q].C = y.P + (int64_t)(j0 + nbj[q]) * y.ldp + (j0 + nbj[q]); trail[q].ldc = y.ldp;
+        trail[q].opts.tri = TRI_LOWER;
+      }
     }
+    NK_TRY(launch_potrf_diag_pair(ctx, Ajj, lda, nbj, Li, nsys, jb));
+    NK_TRY(launch_gemm_pair(ctx, false, true, panel, nsys));
+    NK_TRY(launch_gemm_pair(ctx, false, true, trail, nsys));
   }
-  int info = 0;
-  NK_HIP(hipMemcpyAsync(ctx->h_scalars, ctx->d_info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  NK_HIP(hipMemcpyAsync(ctx->h_scalars, ctx->d_info, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   NK_HIP(hipStreamSynchronize(ctx->stream));
-  info = *reinterpret_cast<int*>(ctx->h_scalars);
-  if (info != 0) {
-    set_error("Cholesky: non-positive pivot at index %d of %d (matrix is numerically rank deficient; the reference's "
-              "lstsq would truncate here)", info - 1, m);
-    return NK_ERR_NOT_SPD;
-  }
+  const int* info = reinterpret_cast<const int*>(ctx->h_scalars);
+  for (int q = 0; q < nsys; ++q)
+    if (info[q] != 0) {
+      set_error("Cholesky: non-positive pivot at index %d of %d (system %d is numerically rank deficient; the "
+                "reference's lstsq would truncate here)", info[q] - 1, sys[q].m, q);
+      return NK_ERR_NOT_SPD;
+    }
   return NK_OK;
 }
 
-int cholesky_solve(nk_ctx* ctx, const double* L, int64_t ldl, int m, const double* Linv, double* R, int64_t ldr,
-                   int nrhs) {
+int cholesky_solve_pair(nk_ctx* ctx, const CholSys* sys, int nsys) {
   constexpr int NB = CHOL_NB;
-  const int nblk = (m + NB - 1) / NB;
-  GemmOpts one;
-  one.splitk = 1;
+  NK_REQUIRE(nsys >= 1 && nsys <= 2, "cholesky_solve_pair: 1..2 systems");
+  int nblk = 0;
+  for (int q = 0; q < nsys; ++q) nblk = std::max(nblk, (sys[q].m + NB - 1) / NB);
   // forward: L T = R
   for (int jb = 0; jb < nblk; ++jb) {
     const int j0 = jb * NB;
-    const int nbj = m - j0 < NB ? m - j0 : NB;
-    const double* Li = Linv + (size_t)jb * NB * NB;
-    double* Rj = R + (int64_t)j0 * ldr;
-    NK_TRY(launch_gemm(ctx, false, false, nbj, nrhs, nbj, 1.0, Li, NB, Rj, ldr, 0.0, Rj, ldr, one));
-    const int rem = m - j0 - nbj;
-    if (rem > 0)
-      NK_TRY(launch_gemm(ctx, false, false, rem, nrhs, nbj, -1.0, L + (int64_t)(j0 + nbj) * ldl + j0, ldl, Rj, ldr,
-                         1.0, R + (int64_t)(j0 + nbj) * ldr, ldr, one));
+    GemmCall diag[2], upd[2];
+    for (int q = 0; q < nsys; ++q) {
+      const CholSys& y = sys[q];
+      if (j0 >= y.m) continue;
+      const int nbj = y.m - j0 < NB ? y.m - j0 : NB;
+      const double* Li = y.Linv + (size_t)jb * NB * NB;
+      double* Rj = y.R + (int64_t)j0 * y.ldr;
+      diag[q].M = nbj; diag[q].N = y.nrhs; diag[q].K = nbj; diag[q].A = Li; diag[q].lda = NB; diag[q].B = Rj;
+      diag[q].ldb = y.ldr; diag[q].C = Rj; diag[q].ldc = y.ldr;
+      const int rem = y.m - j0 - nbj;
+      if (rem > 0) {
+        upd[q].M = rem; upd[q].N = y.nrhs; upd[q].K = nbj; upd[q].alpha = -1.0; upd[q].beta = 1.0;
+        upd[q].A = y.P + (int64_t)(j0 + nbj) * y.ldp + j0; upd[q].lda = y.ldp; upd[q].B = Rj; upd[q].ldb = y.ldr;
+        upd[q].C = y.R + (int64_t)(j0 + nbj) * y.ldr; upd[q].ldc = y.ldr;
+      }
+    }
+    NK_TRY(launch_gemm_pair(ctx, false, false, diag, nsys));
+    NK_TRY(launch_gemm_pair(ctx, false, false, upd, nsys));
   }
   // backward: L^T X = T
   for (int jb = nblk - 1; jb >= 0; --jb) {
     const int j0 = jb * NB;
-    const int nbj = m - j0 < NB ? m - j0 : NB;
-    const double* Li = Linv + (size_t)jb * NB * NB;
-    double* Rj = R + (int64_t)j0 * ldr;
-    NK_TRY(launch_gemm(ctx, true, false, nbj, nrhs, nbj, 1.0, Li, NB, Rj, ldr, 0.0, Rj, ldr, one));
-    if (j0 > 0)
-      NK_TRY(launch_gemm(ctx, true, false, j0, nrhs, nbj, -1.0, L + (int64_t)j0 * ldl, ldl, Rj, ldr, 1.0, R, ldr, one));
+    GemmCall diag[2], upd[2];
+    for (int q = 0; q < nsys; ++q) {
+      const CholSys& y = sys[q];
+      if (j0 >= y.m) continue;
+      const int nbj = y.m - j0 < NB ? y.m - j0 : NB;
+      const double* Li = y.Linv + (size_t)jb * NB * NB;
+      double* Rj = y.R + (int64_t)j0 * y.ldr;
+      diag[q].M = nbj; diag[q].N = y.nrhs; diag[q].K = nbj; diag[q].A = Li; diag[q].lda = NB; diag[q].B = Rj;
+      diag[q].ldb = y.ldr; diag[q].C = Rj; diag[q].ldc = y.ldr;
+      if (j0 > 0) {
+        upd[q].M = j0; upd[q].N = y.nrhs; upd[q].K = nbj; upd[q].alpha = -1.0; upd[q].beta = 1.0;
+        upd[q].A = y.P + (int64_t)j0 * y.ldp; upd[q].lda = y.ldp; upd[q].B = Rj; upd[q].ldb = y.ldr;
+        upd[q].C = y.R; upd[q].ldc = y.ldr;
+      }
+    }
+    NK_TRY(launch_gemm_pair(ctx, true, false, diag, nsys));
+    NK_TRY(launch_gemm_pair(ctx, true, false, upd, nsys));
   }
   return NK_OK;
+}
+
+int cholesky_lower(nk_ctx* ctx, double* P, int64_t ldp, int m, double* Linv) {
+  CholSys y;
+  y.P = P; y.ldp = ldp; y.m = m; y.Linv = Linv;
+  return cholesky_lower_pair(ctx, &y, 1);
+}
+
+int cholesky_solve(nk_ctx* ctx, const double* L, int64_t ldl, int m, const double* Linv, double* R, int64_t ldr,
+                   int nrhs) {
+  CholSys y;
+  y.P = const_cast<double*>(L); y.ldp = ldl; y.m = m; y.Linv = const_cast<double*>(Linv); y.R = R; y.ldr = ldr;
+  y.nrhs = nrhs;
+  return cholesky_solve_pair(ctx, &y, 1);
 }
 
 }  // namespace nk

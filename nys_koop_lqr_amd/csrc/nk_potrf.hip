@@ -16,9 +16,23 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
   return __hiloint2double(hi, lo);
 }
 
-__global__ void __launch_bounds__(64) potrf_diag_kernel(double* __restrict__ A, int64_t lda, int nb,
-                                                        double* __restrict__ Linv, int* __restrict__ info, int blk) {
+struct PotrfBatch {
+  double* A[2];
+  int64_t lda[2];
+  int nb[2];
+  double* Linv[2];
+  int* info[2];
+};
+
+__global__ void __launch_bounds__(64) potrf_diag_kernel(PotrfBatch pb, int blk) {
   constexpr int NB = CHOL_NB;
+  const int which = blockIdx.x;  // one wave per system of a paired factorisation
+  const int nb = pb.nb[which];
+  if (nb <= 0) return;
+  double* __restrict__ A = pb.A[which];
+  const int64_t lda = pb.lda[which];
+  double* __restrict__ Linv = pb.Linv[which];
+  int* __restrict__ info = pb.info[which];
   static_assert(NB == 64, "one lane per row");
   __shared__ double Ls[NB * (NB + 1)];
   __shared__ double dinv[NB];
@@ -75,8 +89,19 @@ __global__ void __launch_bounds__(64) potrf_diag_kernel(double* __restrict__ A, 
   for (int i = 0; i < NB; ++i) Linv[i * NB + lane] = X[i];
 }
 
-int launch_potrf_diag(nk_ctx* ctx, double* Ajj, int64_t lda, int nb, double* Linv, int blk) {
-  hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(64), 0, ctx->stream, Ajj, lda, nb, Linv, ctx->d_info, blk);
+// Ajj/lda/nb/Linv: per system (nb <= 0 skips a system); failures are flagged in ctx->d_info[system]
+int launch_potrf_diag_pair(nk_ctx* ctx, double* const* Ajj, const int64_t* lda, const int* nb, double* const* Linv,
+                           int nsys, int blk) {
+  PotrfBatch pb;
+  for (int q = 0; q < 2; ++q) {
+    const bool on = q < nsys;
+    pb.A[q] = on ? Ajj[q] : nullptr;
+    pb.lda[q] = on ? lda[q] : 0;
+    pb.nb[q] = on ? nb[q] : 0;
+    pb.Linv[q] = on ? Linv[q] : nullptr;
+    pb.info[q] = ctx->d_info + q;
+  }
+  hipLaunchKernelGGL(potrf_diag_kernel, dim3(2), dim3(64), 0, ctx->stream, pb, blk);
   NK_HIP(hipGetLastError());
   return NK_OK;
 }

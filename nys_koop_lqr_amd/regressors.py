@@ -4,6 +4,7 @@ public attributes, same fit / lift / predict shapes and error behaviour, so that
 kernels of libnyskoop.so through ctypes.  The DARE (control.dlqr in the reference) stays on the host.
 """
 import ctypes as C
+import time
 
 import numpy as np
 from sklearn.base import BaseEstimator
@@ -160,7 +161,9 @@ class KoopmanNystromRegressor(KoopmanRegressor):
             rr, n_rr = flat.ctypes.data_as(C.POINTER(C.c_int64)), flat.size // 2
         stats = _lib.FitStats()
         h = C.c_void_p()
+        t_host0 = time.perf_counter()
         self._drop_model()
+        t_host1 = time.perf_counter()
         rc = ctx.lib.nk_nystrom_fit(ctx.handle, C.byref(kd), Xm.ptr, Xm.ld, Ym.ptr, Ym.ld, n, d, p, rr, n_rr,
                                     None if same else Zi.ctypes.data, d, Zo.ctypes.data, d, m,
                                     float(self.gamma), float(self.jitter), C.byref(h), C.byref(stats))
@@ -169,6 +172,7 @@ class KoopmanNystromRegressor(KoopmanRegressor):
         if rc == -3:
             raise np.linalg.LinAlgError(ctx.lib.nk_last_error().decode())
         _lib.check(rc)
+        t_host2 = time.perf_counter()
         self._model = h
         self._stats = stats.as_dict()
         G = np.empty((m, m + p))
@@ -182,6 +186,9 @@ class KoopmanNystromRegressor(KoopmanRegressor):
         G[:, :m], G[:, m:] = A, B
         self.A = G[:, :m]  # views of G_ls, as in regressors.py:158-159
         self.B = G[:, m:]
+        t_host3 = time.perf_counter()
+        self._stats.update(host_ms_drop=(t_host1 - t_host0) * 1e3, host_ms_call=(t_host2 - t_host1) * 1e3,
+                           host_ms_fetch=(t_host3 - t_host2) * 1e3)
         self._model_key = (id(self.nystrom_centers_output), id(self.A), id(self.B), id(self.C), id(self.weights))
 
     # ------------------------------------------------------------------------------------------------ lift / predict

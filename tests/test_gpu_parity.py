@@ -166,6 +166,32 @@ def test_fit_lift_predict_vs_reference_golden(nk, O, golden, name, p, tol, tolp)
     assert pred.shape == g["predict"].shape and relf(pred, g["predict"]) < tolp, relf(pred, g["predict"])
 
 
+def test_gram_form_kernel_blocks_match_direct_differences(nk, O, golden):
+    """The two n x m kernel blocks of the fit: Gram form on the MFMA engine (default for d >= 32) against the
+    direct-difference build (what cdist does): both meet the reference, and agree with each other far below the bar."""
+    g = golden("f2_synth_rbf_d384.npz")
+    ctx = nk.get_context()
+    res = {}
+    try:
+        for mode in (1, 0):
+            ctx.set_kmat_mode(mode)
+            reg, X, Y, d = _fit(nk, O, "rbf", g, 6)
+            res[mode] = reg
+            assert max(relf(reg.A, g["A"]), relf(reg.C, g["C"]), relf(reg.weights, g["W"])) < 1e-8
+    finally:
+        ctx.set_kmat_mode(0)
+    assert relf(res[0].A, res[1].A) < 1e-9 and relf(res[0].weights, res[1].weights) < 1e-9
+    g1 = golden("f1_cloth_rbf_wellcond.npz")  # anisotropic l = (1, 10, 100): large scaled norms
+    try:
+        for mode in (1, 0):
+            ctx.set_kmat_mode(mode)
+            reg, X, Y, d = _fit(nk, O, "rbf", g1, 6)
+            res[mode] = reg
+    finally:
+        ctx.set_kmat_mode(0)
+    assert relf(res[0].weights, res[1].weights) < 1e-7 and relf(res[0].predict(X[:50]), res[1].predict(X[:50])) < 1e-9
+
+
 def test_rollout_forms_and_pickle(nk, O, golden):
     g = golden("f1_cloth_rbf_wellcond.npz")
     reg, X, Y, d = _fit(nk, O, "rbf", g, 6)
