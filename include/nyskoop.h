@@ -84,6 +84,11 @@ void* nk_stream(nk_ctx* ctx);
  * Also settable with the environment variable NYSKOOP_KMAT=direct before nk_create. */
 int nk_set_kmat_mode(nk_ctx* ctx, int mode);
 
+/* page-locked host memory for result arrays (device->host copies into it run at the PCIe rate and skip first-touch
+ * page faults); nk_host_free(NULL) is a no-op. */
+void* nk_host_alloc(uint64_t bytes);
+void nk_host_free(void* ptr);
+
 /* ---- kernel matrix: replaces `kern.kernel(A, B)` (regressors.py:22,26,30 -> sklearn RBF/Matern/DotProduct
  *      __call__): out[i][j] = k(A[i,:], B[j,:]),  A: nA x d, B: nB x d, out: nA x nB. ------------------------ */
 int nk_kernel_matrix(nk_ctx* ctx, const nk_kernel_desc* kd,

@@ -50,6 +50,8 @@ SIGNATURES = {
     "nk_synchronize": (C.c_int, [_P]),
     "nk_stream": (_P, [_P]),
     "nk_set_kmat_mode": (C.c_int, [_P, C.c_int]),
+    "nk_host_alloc": (_P, [C.c_uint64]),
+    "nk_host_free": (None, [_P]),
     "nk_kernel_matrix": (C.c_int, [_P, C.POINTER(KernelDesc), _P, _I64, _I64, _P, _I64, _I64, _P, _I64]),
     "nk_nystrom_fit": (C.c_int, [_P, C.POINTER(KernelDesc), _P, _I64, _P, _I64, _I64, _I32, _I32,
                                  C.POINTER(_I64), _I32, _P, _I64, _P, _I64, _I32, _D, _D,
@@ -160,6 +162,42 @@ class Context:
     def set_kmat_mode(self, mode):
         """0 = automatic (Gram form on the MFMA engine for d >= 32), 1 = always direct differences."""
         check(self.lib.nk_set_kmat_mode(self.handle, int(mode)))
+
+
+class _PinnedBlock:
+    """A page-locked host block that returns to a small pool when its last array view dies."""
+    _pool = {}
+
+    def __init__(self, nbytes):
+        self.nbytes = int(nbytes)
+        free = _PinnedBlock._pool.get(self.nbytes)
+        if free:
+            self.ptr = free.pop()
+        else:
+            self.ptr = load_library().nk_host_alloc(self.nbytes)
+            if not self.ptr:
+                raise MemoryError(f"nk_host_alloc({self.nbytes}) failed")
+
+    def __del__(self):
+        try:
+            free = _PinnedBlock._pool.setdefault(self.nbytes, [])
+            if len(free) < 8:
+                free.append(self.ptr)
+            else:
+                load_library().nk_host_free(self.ptr)
+        except Exception:
+            pass
+
+
+def pinned_empty(shape):
+    """float64 C-contiguous ndarray backed by page-locked memory (results of fit land here)."""
+    n = int(np.prod(shape))
+    if n == 0:
+        return np.empty(shape)
+    block = _PinnedBlock(n * 8)
+    buf = (C.c_double * n).from_address(block.ptr)
+    buf._nk_owner = block  # the ctypes array is the ndarray's base and keeps the block alive
+    return np.frombuffer(buf, dtype=np.float64).reshape(shape)
 
 
 _contexts = {}

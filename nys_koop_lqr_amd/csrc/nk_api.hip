@@ -391,6 +391,20 @@ int nk_synchronize(nk_ctx* ctx) {
 
 void* nk_stream(nk_ctx* ctx) { return ctx ? reinterpret_cast<void*>(ctx->stream) : nullptr; }
 
+void* nk_host_alloc(uint64_t bytes) {
+  void* p = nullptr;
+  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+    (void)hipGetLastError();
+    set_error("hipHostMalloc of %llu bytes failed", (unsigned long long)bytes);
+    return nullptr;
+  }
+  return p;
+}
+
+void nk_host_free(void* ptr) {
+  if (ptr) (void)hipHostFree(ptr);
+}
+
 int nk_set_kmat_mode(nk_ctx* ctx, int mode) {
   NK_REQUIRE(ctx != nullptr && (mode == 0 || mode == 1), "nk_set_kmat_mode: bad argument");
   ctx->kmat_mode = mode;
@@ -674,6 +688,8 @@ int nk_nystrom_fit(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int64
                         2.0 * ne * (double)d * m;
     stats->kmat_pairs = 2.0 * ne * m * d + (same_centers ? 1.0 : 3.0) * (double)m * m * d;
   }
+  tr.mark("stats");
+  if (ctx->arena.chunks.size() > 1) NK_TRY(arena_reset(ctx));  // coalesce now (everything is synchronised), not in the next call
   guard.m = nullptr;
   *model = mdl;
   return NK_OK;

@@ -175,17 +175,14 @@ class KoopmanNystromRegressor(KoopmanRegressor):
         t_host2 = time.perf_counter()
         self._model = h
         self._stats = stats.as_dict()
-        G = np.empty((m, m + p))
-        self.C = np.empty((d, m))
-        self.weights = np.empty((d, m + p))
-        A = np.empty((m, m))
-        B = np.empty((m, p))
-        for which, arr in (("A", A), ("B", B), ("C", self.C), ("W", self.weights)):
-            if arr.size:
-                _lib.check(ctx.lib.nk_model_get(ctx.handle, h, which.encode(), arr.ctypes.data, arr.shape[1]))
-        G[:, :m], G[:, m:] = A, B
+        G = _lib.pinned_empty((m, m + p))  # page-locked: the device->host copies run at the PCIe rate
+        self.C = _lib.pinned_empty((d, m))
+        self.weights = _lib.pinned_empty((d, m + p))
         self.A = G[:, :m]  # views of G_ls, as in regressors.py:158-159
         self.B = G[:, m:]
+        for which, arr in (("A", self.A), ("B", self.B), ("C", self.C), ("W", self.weights)):
+            if arr.size:
+                _lib.check(ctx.lib.nk_model_get(ctx.handle, h, which.encode(), arr.ctypes.data, arr.strides[0] // 8))
         t_host3 = time.perf_counter()
         self._stats.update(host_ms_drop=(t_host1 - t_host0) * 1e3, host_ms_call=(t_host2 - t_host1) * 1e3,
                            host_ms_fetch=(t_host3 - t_host2) * 1e3)
