@@ -161,6 +161,12 @@ int nk_sqrtm_spd(nk_ctx* ctx, const double* P, int64_t ldp, int32_t m, double* S
 int nk_solve_spd(nk_ctx* ctx, const double* P, int64_t ldp, int32_t m, const double* R, int64_t ldr,
                  int32_t nrhs, double* X, int64_t ldxo);
 
+/* ---- diagnostics ---------------------------------------------------------------------------------------- */
+/* Runs `reps` fused Gram launches (the dominant kernel of nk_nystrom_fit) on a synthetic n x (2m+p) feature matrix and
+ * n x d targets resident in HBM; returns the average kernel time (HIP events on the context's stream) and the
+ * algorithmic flop of one launch.  For rocprofv3 --pmc runs that should not pay for a whole fit. */
+int nk_bench_gram(nk_ctx* ctx, int64_t n, int32_t m, int32_t p, int32_t d, int32_t reps, double* ms_avg, double* flop);
+
 #ifdef __cplusplus
 }
 #endif

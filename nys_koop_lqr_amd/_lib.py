@@ -69,6 +69,7 @@ SIGNATURES = {
     "nk_gemm": (C.c_int, [_P, C.c_int, C.c_int, _I64, _I64, _I64, _D, _P, _I64, _P, _I64, _D, _P, _I64]),
     "nk_sqrtm_spd": (C.c_int, [_P, _P, _I64, _I32, _P, _P, C.POINTER(_I32), C.POINTER(_D)]),
     "nk_solve_spd": (C.c_int, [_P, _P, _I64, _I32, _P, _I64, _I32, _P, _I64]),
+    "nk_bench_gram": (C.c_int, [_P, _I64, _I32, _I32, _I32, _I32, C.POINTER(_D), C.POINTER(_D)]),
 }
 
 _lib = None

@@ -975,4 +975,50 @@ int nk_solve_spd(nk_ctx* ctx, const double* P, int64_t ldp, int32_t m, const dou
   return NK_OK;
 }
 
+__global__ void nk_fill_pattern_kernel(double* p, int64_t n, unsigned seed) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    unsigned long long x = (unsigned long long)i * 6364136223846793005ULL + seed * 1442695040888963407ULL + 1;
+    x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ULL; x ^= x >> 32;
+    p[i] = (double)(x >> 11) * (1.0 / 9007199254740992.0) - 0.5;  // uniform [-0.5, 0.5), full mantissa
+  }
+}
+
+int nk_bench_gram(nk_ctx* ctx, int64_t n, int32_t m, int32_t p, int32_t d, int32_t reps, double* ms_avg, double* flop) {
+  NK_TRY(check_ctx(ctx));
+  NK_REQUIRE(n > 0 && m > 0 && p >= 0 && d > 0 && reps > 0 && ms_avg, "nk_bench_gram: bad argument");
+  const int mp = m + p;
+  const int64_t off_out = (mp + 1) & ~1;
+  const int64_t ldf = (off_out + m + 1) & ~(int64_t)1;
+  const int64_t ldd = d + (d & 1);
+  double *F = nullptr, *Y = nullptr, *G1 = nullptr, *G2t = nullptr, *G3 = nullptr, *G4t = nullptr;
+  NK_TRY(arena_alloc_t(ctx, (size_t)n * ldf + 64, &F));
+  NK_TRY(arena_alloc_t(ctx, (size_t)n * ldd, &Y));
+  NK_TRY(arena_alloc_t(ctx, (size_t)mp * mp, &G1));
+  NK_TRY(arena_alloc_t(ctx, (size_t)mp * m, &G2t));
+  NK_TRY(arena_alloc_t(ctx, (size_t)m * m, &G3));
+  NK_TRY(arena_alloc_t(ctx, (size_t)m * ldd, &G4t));
+  hipLaunchKernelGGL(nk_fill_pattern_kernel, dim3(4096), dim3(256), 0, ctx->stream, F, n * ldf, 1u);
+  hipLaunchKernelGGL(nk_fill_pattern_kernel, dim3(4096), dim3(256), 0, ctx->stream, Y, n * ldd, 2u);
+  NK_HIP(hipGetLastError());
+  TnProblem pr[4];
+  pr[0].A = F; pr[0].B = F; pr[0].lda = pr[0].ldb = ldf; pr[0].M = pr[0].N = mp; pr[0].C = G1; pr[0].ldc = mp;
+  pr[0].tri = TRI_UPPER_MIRROR;
+  pr[1].A = F; pr[1].B = F + off_out; pr[1].lda = pr[1].ldb = ldf; pr[1].M = mp; pr[1].N = m; pr[1].C = G2t; pr[1].ldc = m;
+  pr[2].A = F + off_out; pr[2].B = F + off_out; pr[2].lda = pr[2].ldb = ldf; pr[2].M = pr[2].N = m; pr[2].C = G3;
+  pr[2].ldc = m; pr[2].tri = TRI_UPPER_MIRROR;
+  pr[3].A = F + off_out; pr[3].lda = ldf; pr[3].M = m; pr[3].N = d; pr[3].C = G4t; pr[3].ldc = ldd; pr[3].B = Y;
+  pr[3].ldb = ldd;
+  for (int q = 0; q < 4; ++q) NK_REQUIRE(tn_fast_ok(pr[q]), "nk_bench_gram: shape violates the alignment contract");
+  double total = 0.0;
+  for (int r = 0; r < reps + 1; ++r) {
+    float ms = 0.f;
+    NK_TRY(launch_gemm_tn_multi(ctx, pr, 4, n, 0, &ms));
+    if (r > 0) total += ms;
+  }
+  NK_HIP(hipStreamSynchronize(ctx->stream));
+  *ms_avg = total / reps;
+  if (flop) *flop = ((double)mp * (mp + 1) + 2.0 * m * mp + (double)m * (m + 1) + 2.0 * d * m) * (double)n;
+  return NK_OK;
+}
+
 }  // extern "C"

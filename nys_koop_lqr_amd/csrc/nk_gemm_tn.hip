@@ -34,6 +34,9 @@ struct TnDev {
   int tiles_n;     // tiles along N
   int tri;
   int tile_begin;  // first global tile index of this problem
+  double* C;       // direct epilogue (splitk == 1): C = alpha * acc + beta * C
+  int64_t ldc;
+  double alpha, beta;
 };
 struct TnParams {
   TnDev p[TN_MAXP];
@@ -67,7 +70,17 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_f64_kernel(TnParams P) {
     if (q < P.nprob && gt >= P.p[q].tile_begin) pi = q;
   const TnDev pr = P.p[pi];
   int tm, tn;
-  {
+  if (EPI == 1) {
+    // kernel-matrix launch: blocks b, b+8, ... share an XCD (round-robin dispatch), so give every XCD group its own
+    // landmark tile columns tn = xcd + 8c for all sample tiles tm: the landmark panels (2 x 393 KB at m = 2000,
+    // d = 384) stay resident in that XCD's L2 while the sample panels stream through once per group
+    const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;
+    const int cols = (pr.tiles_n - xcd + 7) >> 3;
+    if (cols <= 0) return;
+    tm = i / cols;
+    tn = xcd + 8 * (i - tm * cols);
+    if (tm * TBM >= pr.M) return;
+  } else {
     const int t = gt - pr.tile_begin;
     if (pr.tri == TRI_FULL) {
       tm = t / pr.tiles_n;
@@ -143,7 +156,25 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_f64_kernel(TnParams P) {
     }
   }
 
-  if (EPI == 0) {
+  if (EPI == 0 && P.splitk == 1) {
+    // single K slice: finish in place (alpha/beta, bounds, symmetric mirror), no slab round trip
+    const bool mirror = pr.tri == TRI_UPPER_MIRROR && tm != tn;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int row = tm * TBM + wm * 64 + i * 16 + g4 + 4 * reg;
+          const int col = tn * TBM + wn * 64 + j * 16 + r16;
+          if (row < pr.M && col < pr.N) {
+            double v = pr.alpha * acc[i][j][reg];
+            if (pr.beta != 0.0) v += pr.beta * pr.C[(int64_t)row * pr.ldc + col];
+            pr.C[(int64_t)row * pr.ldc + col] = v;
+            if (mirror) pr.C[(int64_t)col * pr.ldc + row] = v;
+          }
+        }
+  } else if (EPI == 0) {
     // raw 128x128 partial tile -> slab[(tile*splitk + split)]
     double* out = P.slab + ((int64_t)gt * P.splitk + split) * (TBM * TBM);
 #pragma unroll
@@ -302,6 +333,7 @@ int launch_gemm_tn_multi(nk_ctx* ctx, const TnProblem* probs, int nprob, int64_t
     TnDev& d = P.p[q];
     d.A = s.A; d.B = s.B; d.lda = s.lda; d.ldb = s.ldb; d.M = s.M; d.N = s.N;
     d.tiles_n = tnn; d.tri = s.tri; d.tile_begin = ntiles;
+    d.C = s.C; d.ldc = s.ldc; d.alpha = s.alpha; d.beta = s.beta;
     TnRed& r = R.p[q];
     r.C = s.C; r.ldc = s.ldc; r.M = s.M; r.N = s.N; r.tiles_n = tnn; r.tri = s.tri; r.tile_begin = ntiles;
     r.alpha = s.alpha; r.beta = s.beta;
@@ -331,7 +363,7 @@ int launch_gemm_tn_multi(nk_ctx* ctx, const TnProblem* probs, int nprob, int64_t
       double t = full * 2.44 * steps;
       if (rem > 0) t += (rem <= ctx->num_cu ? 2.35 : 2.44) * steps;
       t *= 4096.0;                                                      // cycles of MFMA per k-step and wave
-      t += (double)wgs * (TBM * TBM * 8.0 * 2.0) / 4.0e12 * 2.4e9;       // slab write + read, in cycles
+      if (c > 1) t += (double)wgs * (TBM * TBM * 8.0 * 2.0) / 4.0e12 * 2.4e9;  // slab write + read, in cycles
       t += 2000.0 * c / 8.0;                                            // mild preference for fewer slices
       if (c % 8 == 0) t *= 0.97;
       if (t < best) { best = t; splitk = c; }
@@ -343,7 +375,7 @@ int launch_gemm_tn_multi(nk_ctx* ctx, const TnProblem* probs, int nprob, int64_t
   P.zeros = ctx->d_zeros;
   const ArenaMark mark = arena_mark(ctx);
   double* slab = nullptr;
-  NK_TRY(arena_alloc_t(ctx, (size_t)ntiles * splitk * TBM * TBM, &slab));
+  if (splitk > 1) NK_TRY(arena_alloc_t(ctx, (size_t)ntiles * splitk * TBM * TBM, &slab));
   P.slab = slab;
   R.nprob = nprob; R.splitk = splitk; R.slab = slab;
   if (!g_tn_attr_set) {
@@ -358,8 +390,10 @@ int launch_gemm_tn_multi(nk_ctx* ctx, const TnProblem* probs, int nprob, int64_t
   hipLaunchKernelGGL(gemm_tn_f64_kernel<0>, dim3((unsigned)(ntiles * splitk)), dim3(256), TN_LDS_BYTES, ctx->stream, P);
   NK_HIP(hipGetLastError());
   if (ms_kernel) NK_HIP(hipEventRecord(ctx->ev[15], ctx->stream));
-  hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, R);
-  NK_HIP(hipGetLastError());
+  if (splitk > 1) {
+    hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, R);
+    NK_HIP(hipGetLastError());
+  }
   if (ms_kernel) {
     NK_HIP(hipEventSynchronize(ctx->ev[15]));
     NK_HIP(hipEventElapsedTime(ms_kernel, ctx->ev[14], ctx->ev[15]));
@@ -458,6 +492,7 @@ int launch_kmat_gram(nk_ctx* ctx, int ktype, const double* At, int64_t ldat, con
   TnDev& dv = P.p[0];
   dv.A = At; dv.B = Bt; dv.lda = ldat; dv.ldb = ldbt; dv.M = (int)nA; dv.N = (int)nB; dv.tiles_n = tnn; dv.tri = TRI_FULL;
   dv.tile_begin = 0;
+  dv.C = nullptr; dv.ldc = 0; dv.alpha = 1.0; dv.beta = 0.0;
   for (int q = 1; q < TN_MAXP; ++q) { P.p[q] = P.p[0]; P.p[q].tile_begin = 1 << 30; }
   P.nprob = 1; P.ntiles = tmn * tnn; P.K = d; P.splitk = 1;
   P.klen = ((d + TBK - 1) / TBK) * TBK;
@@ -470,7 +505,8 @@ int launch_kmat_gram(nk_ctx* ctx, int ktype, const double* At, int64_t ldat, con
                                hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES));
     g_tn_attr_set = true;
   }
-  hipLaunchKernelGGL(gemm_tn_f64_kernel<1>, dim3((unsigned)P.ntiles), dim3(256), TN_LDS_BYTES, ctx->stream, P);
+  const unsigned grid = 8u * (unsigned)tmn * (unsigned)((tnn + 7) / 8);
+  hipLaunchKernelGGL(gemm_tn_f64_kernel<1>, dim3(grid), dim3(256), TN_LDS_BYTES, ctx->stream, P);
   NK_HIP(hipGetLastError());
   return NK_OK;
 }

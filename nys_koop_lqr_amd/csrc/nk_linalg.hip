@@ -342,8 +342,18 @@ int sqrtm_spd(nk_ctx* ctx, const double* P, int64_t ldp, int m, double* S, doubl
     }
     NK_TRY(launch_scale_add_identity(ctx, -0.5 * s2 * sc, M, m, 1.5 * sc, T, m, m));
     NK_TRY(launch_transpose(ctx, Y, m, Xt, m, m, m));
-    NK_TRY(launch_gemm(ctx, true, false, m, m, m, 1.0, Xt, m, T, m, 0.0, Yn, m));   // Y T
-    NK_TRY(launch_gemm(ctx, true, false, m, m, m, 1.0, T, m, Z, m, 0.0, Zn, m));    // T Z (T is exactly symmetric)
+    {
+      // Y T and T Z (T is exactly symmetric) share K = m: one fused launch, 2 x 256 tiles = two workgroups per CU
+      TnProblem pr[2];
+      pr[0].A = Xt; pr[0].B = T; pr[0].C = Yn; pr[0].lda = pr[0].ldb = pr[0].ldc = m; pr[0].M = pr[0].N = m;
+      pr[1].A = T; pr[1].B = Z; pr[1].C = Zn; pr[1].lda = pr[1].ldb = pr[1].ldc = m; pr[1].M = pr[1].N = m;
+      if (tn_fast_ok(pr[0]) && tn_fast_ok(pr[1]) && m >= 128) {
+        NK_TRY(launch_gemm_tn_multi(ctx, pr, 2, m, 0));
+      } else {
+        NK_TRY(launch_gemm(ctx, true, false, m, m, m, 1.0, Xt, m, T, m, 0.0, Yn, m));
+        NK_TRY(launch_gemm(ctx, true, false, m, m, m, 1.0, T, m, Z, m, 0.0, Zn, m));
+      }
+    }
     double* t = Y; Y = Yn; Yn = t;
     t = Z; Z = Zn; Zn = t;
   }
