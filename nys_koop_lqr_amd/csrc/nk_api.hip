@@ -36,7 +36,7 @@ bool is_device_ptr(const void* p) {
 }
 
 // ---- arena -----------------------------------------------------------------------------------------------------
-static int arena_new_chunk(nk_ctx* ctx, size_t bytes) {
+static int arena_new_chunk(nk_ctx* ctx, Arena& a, size_t bytes) {
   ArenaChunk c;
   c.cap = bytes;
   hipError_t e = hipMalloc(reinterpret_cast<void**>(&c.base), bytes);
@@ -45,35 +45,42 @@ static int arena_new_chunk(nk_ctx* ctx, size_t bytes) {
     set_error("HBM workspace allocation of %zu bytes failed: %s", bytes, hipGetErrorString(e));
     return NK_ERR_OOM;
   }
-  ctx->arena.chunks.push_back(c);
+  a.chunks.push_back(c);
   return NK_OK;
 }
 
-int arena_reset(nk_ctx* ctx) {
-  Arena& a = ctx->arena;
+static int arena_reset_one(nk_ctx* ctx, Arena& a) {
   if (a.chunks.size() > 1) {  // coalesce: steady state is one chunk and no hipMalloc on the hot path
-    NK_HIP(hipStreamSynchronize(ctx->stream));
+    NK_HIP(hipStreamSynchronize(ctx->stream_main));
+    NK_HIP(hipStreamSynchronize(ctx->stream_side));
     size_t total = 0;
     for (auto& c : a.chunks) {
       total += c.cap;
       (void)hipFree(c.base);
     }
     a.chunks.clear();
-    NK_TRY(arena_new_chunk(ctx, total));
+    NK_TRY(arena_new_chunk(ctx, a, total));
   }
   for (auto& c : a.chunks) c.off = 0;
   a.cur = 0;
   return NK_OK;
 }
 
+int arena_reset(nk_ctx* ctx) {
+  ctx->stream = ctx->stream_main;
+  ctx->cur_arena = &ctx->arena;
+  NK_TRY(arena_reset_one(ctx, ctx->arena));
+  return arena_reset_one(ctx, ctx->arena_side);
+}
+
 ArenaMark arena_mark(nk_ctx* ctx) {
-  Arena& a = ctx->arena;
+  Arena& a = *ctx->cur_arena;
   if (a.chunks.empty()) return ArenaMark{0, 0};
   return ArenaMark{a.cur, a.chunks[a.cur].off};
 }
 
 void arena_release(nk_ctx* ctx, ArenaMark mk) {
-  Arena& a = ctx->arena;
+  Arena& a = *ctx->cur_arena;
   if (a.chunks.empty()) return;
   for (int i = mk.chunk + 1; i < (int)a.chunks.size(); ++i) a.chunks[i].off = 0;
   a.cur = mk.chunk;
@@ -81,7 +88,7 @@ void arena_release(nk_ctx* ctx, ArenaMark mk) {
 }
 
 int arena_alloc(nk_ctx* ctx, size_t bytes, void** out) {
-  Arena& a = ctx->arena;
+  Arena& a = *ctx->cur_arena;
   bytes = (bytes + 255) & ~(size_t)255;
   if (bytes == 0) bytes = 256;
   for (;;) {
@@ -102,7 +109,7 @@ int arena_alloc(nk_ctx* ctx, size_t bytes, void** out) {
     const size_t min_chunk = (size_t)256 << 20;
     if (want < min_chunk) want = min_chunk;
     if (!a.chunks.empty() && want < a.chunks.back().cap) want = a.chunks.back().cap;
-    NK_TRY(arena_new_chunk(ctx, want));
+    NK_TRY(arena_new_chunk(ctx, a, want));
     a.cur = (int)a.chunks.size() - 1;
   }
 }
@@ -357,10 +364,20 @@ int nk_create(int device, nk_ctx** out) {
   nk_ctx* ctx = new nk_ctx();
   ctx->device = device;
   ctx->num_cu = prop.multiProcessorCount;
-  NK_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+  // main stream: highest priority (it carries the latency-bound factorisation chains, whose tiny kernels must not queue
+  // behind the GEMM workgroups of the side stream); side stream: lowest priority
+  int prio_lo = 0, prio_hi = 0;
+  NK_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+  NK_HIP(hipStreamCreateWithPriority(&ctx->stream_main, hipStreamNonBlocking, prio_hi));
+  NK_HIP(hipStreamCreateWithPriority(&ctx->stream_side, hipStreamNonBlocking, prio_lo));
+  ctx->stream = ctx->stream_main;
+  ctx->cur_arena = &ctx->arena;
+  NK_HIP(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+  NK_HIP(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
   NK_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->d_info), 256));
   NK_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->d_scalars), 64 * sizeof(double)));
   NK_HIP(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_scalars), 64 * sizeof(double)));
+  NK_HIP(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_info), 64));
   for (int i = 0; i < 16; ++i) NK_HIP(hipEventCreate(&ctx->ev[i]));
   const char* km = getenv("NYSKOOP_KMAT");
   ctx->kmat_mode = (km && strcmp(km, "direct") == 0) ? 1 : 0;
@@ -371,14 +388,20 @@ int nk_create(int device, nk_ctx** out) {
 int nk_destroy(nk_ctx* ctx) {
   if (!ctx) return NK_OK;
   (void)hipSetDevice(ctx->device);
-  (void)hipStreamSynchronize(ctx->stream);
+  (void)hipStreamSynchronize(ctx->stream_main);
+  (void)hipStreamSynchronize(ctx->stream_side);
   for (auto& c : ctx->arena.chunks) (void)hipFree(c.base);
+  for (auto& c : ctx->arena_side.chunks) (void)hipFree(c.base);
+  (void)hipEventDestroy(ctx->ev_fork);
+  (void)hipEventDestroy(ctx->ev_join);
+  (void)hipStreamDestroy(ctx->stream_side);
   (void)hipFree(ctx->d_info);
   (void)hipFree(ctx->d_scalars);
   if (ctx->d_zeros) (void)hipFree(ctx->d_zeros);
   (void)hipHostFree(ctx->h_scalars);
+  (void)hipHostFree(ctx->h_info);
   for (int i = 0; i < 16; ++i) (void)hipEventDestroy(ctx->ev[i]);
-  (void)hipStreamDestroy(ctx->stream);
+  (void)hipStreamDestroy(ctx->stream_main);
   delete ctx;
   return NK_OK;
 }
@@ -482,6 +505,23 @@ int nk_nystrom_fit(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int64
   NK_HIP(hipEventRecord(ev[1], ctx->stream));
   tr.mark("staging issued");
 
+  // ---- landmark kernels (regressors.py:139,143,144) -----------------------------------------------------------------
+  double *Kmm = nullptr, *Kj = nullptr, *Kj_in = nullptr, *Kxo = nullptr;
+  NK_TRY(arena_alloc_t(ctx, (size_t)m * m, &Kmm));
+  NK_TRY(arena_alloc_t(ctx, (size_t)m * m, &Kj));
+  NK_TRY(launch_kmat(ctx, kd->type, zo.ptr, zo.ld, m, zo.ptr, zo.ld, m, d, mdl->winv, kd->sigma0, Kmm, m));
+  NK_TRY(launch_copy2d(ctx, Kmm, m, Kj, m, m, m));
+  NK_TRY(launch_add_diag(ctx, Kj, m, m, jitter));
+  if (same_centers) {
+    Kj_in = Kj;
+    Kxo = Kmm;
+  } else {
+    NK_TRY(arena_alloc_t(ctx, (size_t)m * m, &Kj_in));
+    NK_TRY(arena_alloc_t(ctx, (size_t)m * m, &Kxo));
+    NK_TRY(launch_kmat(ctx, kd->type, zi.ptr, zi.ld, m, zi.ptr, zi.ld, m, d, mdl->winv, kd->sigma0, Kj_in, m));
+    NK_TRY(launch_add_diag(ctx, Kj_in, m, m, jitter));
+    NK_TRY(launch_kmat(ctx, kd->type, zi.ptr, zi.ld, m, zo.ptr, zo.ld, m, d, mdl->winv, kd->sigma0, Kxo, m));
+  }
   // ---- feature matrix F = [K_nm_in | U | (pad) | K_nm_out], sample-major (regressors.py:141-142,147) ------------
   const int64_t off_out = (mp + 1) & ~1;
   const int64_t ldf = (off_out + m + 1) & ~(int64_t)1;
@@ -532,23 +572,6 @@ int nk_nystrom_fit(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int64
       o += len;
     }
   }
-  // ---- landmark kernels (regressors.py:139,143,144) -----------------------------------------------------------------
-  double *Kmm = nullptr, *Kj = nullptr, *Kj_in = nullptr, *Kxo = nullptr;
-  NK_TRY(arena_alloc_t(ctx, (size_t)m * m, &Kmm));
-  NK_TRY(arena_alloc_t(ctx, (size_t)m * m, &Kj));
-  NK_TRY(launch_kmat(ctx, kd->type, zo.ptr, zo.ld, m, zo.ptr, zo.ld, m, d, mdl->winv, kd->sigma0, Kmm, m));
-  NK_TRY(launch_copy2d(ctx, Kmm, m, Kj, m, m, m));
-  NK_TRY(launch_add_diag(ctx, Kj, m, m, jitter));
-  if (same_centers) {
-    Kj_in = Kj;
-    Kxo = Kmm;
-  } else {
-    NK_TRY(arena_alloc_t(ctx, (size_t)m * m, &Kj_in));
-    NK_TRY(arena_alloc_t(ctx, (size_t)m * m, &Kxo));
-    NK_TRY(launch_kmat(ctx, kd->type, zi.ptr, zi.ld, m, zi.ptr, zi.ld, m, d, mdl->winv, kd->sigma0, Kj_in, m));
-    NK_TRY(launch_add_diag(ctx, Kj_in, m, m, jitter));
-    NK_TRY(launch_kmat(ctx, kd->type, zi.ptr, zi.ld, m, zo.ptr, zo.ld, m, d, mdl->winv, kd->sigma0, Kxo, m));
-  }
   NK_HIP(hipEventRecord(ev[2], ctx->stream));
   tr.mark("kmat issued");
 
@@ -563,6 +586,7 @@ int nk_nystrom_fit(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int64
   NK_TRY(arena_alloc_t(ctx, (size_t)m * ldd, &G4t));
   float ms_gram_kernel = 0.f;
   int gram_launches = 0;
+  bool gram_deferred = false;
   const bool timed = stats != nullptr;
   {
     TnProblem pr[4];
@@ -579,7 +603,8 @@ int nk_nystrom_fit(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int64
     const bool fast_y = fast && tn_fast_ok(pr[3]);
     if (fast) {
       const int np = (single && fast_y) ? 4 : 3;
-      NK_TRY(launch_gemm_tn_multi(ctx, pr, np, n_eff, 0, timed ? &ms_gram_kernel : nullptr));
+      NK_TRY(launch_gemm_tn_multi(ctx, pr, np, n_eff, 0, timed ? &ms_gram_kernel : nullptr, false));
+      gram_deferred = timed;
       gram_launches = 1;
       if (np == 3) {
         int64_t oo = 0;
@@ -611,56 +636,66 @@ int nk_nystrom_fit(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int64
     }
   }
   NK_HIP(hipEventRecord(ev[3], ctx->stream));
-  tr.mark("gram issued (+sync if timed)");
+  NK_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));  // the side stream (square root) starts when the Gram launch is done
+  tr.mark("gram issued");
 
-  // ---- S = K_mm^{1/2}, S^{-1} (regressors.py:140,163) ------------------------------------------------------------------
-  int it = 0;
-  double resid = 0.0;
-  NK_TRY(sqrtm_spd(ctx, Kj, m, m, mdl->S, mdl->Sinv, &it, &resid));
-  NK_HIP(hipEventRecord(ev[4], ctx->stream));
-  tr.mark("sqrt done (host-synced)");
-
-  // ---- [A B] = S^-1 (Phi_out Phi_in^T) inner^-1 blkdiag(K_xo S^-1, I)   (regressors.py:151-159) ------------------------
-  // all products are written as P^T Q with P stored contraction-major (the fast TN engine); explicit transposes
-  // where the left factor is not exactly symmetric
+  // ---- the two regularised systems (regressors.py:151,162) are assembled, factorised AND solved on the main stream
+  //      without waiting for the square root: with inner and inner_rec symmetric,
+  //        [A B] = S^-1 (inner^-1 cross^T)^T blkdiag(K_xo S^-1, I)        cross^T = G2t  (regressors.py:152-156)
+  //        C^T   = S^T (inner_rec^-1 left_rec^T)                           left_rec^T = G4t (regressors.py:163-166)
+  //      so the right-hand sides are G2t (m columns) and G4t (only d columns instead of the reference's m).
   NK_TRY(launch_axpby2d(ctx, gamma_n, Kj_in, m, 1.0, G1, mp, m, m));               // inner = G1 + gamma_n*blkdiag(K, I)
   if (p > 0) NK_TRY(launch_add_diag(ctx, G1 + (int64_t)m * mp + m, mp, p, gamma_n));
-  double *right = nullptr, *Linv = nullptr, *T2 = nullptr, *Sinvt = nullptr, *Kxot = nullptr;
+  NK_TRY(launch_axpby2d(ctx, gamma_n, Kj, m, 1.0, G3, m, m, m));                   // inner_rec = gamma_n K + G3
+  double *Linv = nullptr, *Linv2 = nullptr, *Sinvt = nullptr, *T1t = nullptr, *X1 = nullptr, *V2t = nullptr, *Ct = nullptr;
   const int nblk = (mp + CHOL_NB - 1) / CHOL_NB;
-  NK_TRY(arena_alloc_t(ctx, (size_t)mp * mp, &right));
+  const int64_t ldv2 = p + (p & 1) + 2;
   NK_TRY(arena_alloc_t(ctx, (size_t)nblk * CHOL_NB * CHOL_NB, &Linv));
-  NK_TRY(arena_alloc_t(ctx, (size_t)m * mp, &T2));
-  NK_TRY(arena_alloc_t(ctx, (size_t)m * m, &Sinvt));
-  NK_TRY(launch_transpose(ctx, mdl->Sinv, m, Sinvt, m, m, m));
-  if (same_centers) {
-    Kxot = Kxo;  // K(Z,Z) is bitwise symmetric
-  } else {
-    NK_TRY(arena_alloc_t(ctx, (size_t)m * m, &Kxot));
-    NK_TRY(launch_transpose(ctx, Kxo, m, Kxot, m, m, m));
-  }
-  NK_TRY(launch_fill(ctx, right, mp, mp, mp, 0.0));
-  NK_TRY(launch_gemm(ctx, true, false, m, m, m, 1.0, Kxot, m, mdl->Sinv, m, 0.0, right, mp));    // K_xo S^-1
-  if (p > 0) NK_TRY(launch_add_diag(ctx, right + (int64_t)m * mp + m, mp, p, 1.0));
-  // inner_rec = gamma_n K + Phi_out Phi_out^T and its right-hand side S   (regressors.py:162-163)
-  NK_TRY(launch_axpby2d(ctx, gamma_n, Kj, m, 1.0, G3, m, m, m));
-  double *sol_rec = nullptr, *Ct = nullptr, *Linv2 = nullptr;
-  NK_TRY(arena_alloc_t(ctx, (size_t)m * m, &sol_rec));
-  NK_TRY(arena_alloc_t(ctx, (size_t)m * ldd, &Ct));
   NK_TRY(arena_alloc_t(ctx, (size_t)nblk * CHOL_NB * CHOL_NB, &Linv2));
-  NK_TRY(launch_copy2d(ctx, mdl->S, m, sol_rec, m, m, m));
-  // both regularised systems are factorised and solved in lock step (paired launches): the per-block kernels are
-  // latency bound, pairing halves the chain
+  NK_TRY(arena_alloc_t(ctx, (size_t)m * m, &Sinvt));
+  NK_TRY(arena_alloc_t(ctx, (size_t)m * m, &T1t));
+  NK_TRY(arena_alloc_t(ctx, (size_t)m * m, &X1));
+  NK_TRY(arena_alloc_t(ctx, (size_t)m * ldv2, &V2t));
+  NK_TRY(arena_alloc_t(ctx, (size_t)m * ldd, &Ct));
   CholSys sys[2];
-  sys[0].P = G1; sys[0].ldp = mp; sys[0].m = mp; sys[0].Linv = Linv; sys[0].R = right; sys[0].ldr = mp; sys[0].nrhs = mp;
-  sys[1].P = G3; sys[1].ldp = m; sys[1].m = m; sys[1].Linv = Linv2; sys[1].R = sol_rec; sys[1].ldr = m; sys[1].nrhs = m;
-  NK_TRY(cholesky_lower_pair(ctx, sys, 2));
-  NK_TRY(cholesky_solve_pair(ctx, sys, 2));                                                       // sol, sol_rec
-  NK_TRY(launch_gemm(ctx, true, false, m, mp, mp, 1.0, G2t, m, right, mp, 0.0, T2, mp));          // cross * sol
-  NK_TRY(launch_gemm(ctx, true, false, m, mp, m, 1.0, Sinvt, m, T2, mp, 0.0, mdl->A, mp));        // G = S^-1 (.)
-  // ---- C = (Y Phi_out^T) inner_rec^-1 S   (regressors.py:164-166) -------------------------------------------------------
-  NK_TRY(launch_gemm(ctx, true, false, d, m, m, 1.0, G4t, ldd, sol_rec, m, 0.0, mdl->C, m));      // C = left_rec sol_rec
-  NK_TRY(launch_transpose(ctx, mdl->C, m, Ct, ldd, d, m));
-  NK_TRY(launch_gemm(ctx, true, false, d, mp, m, 1.0, Ct, ldd, mdl->A, mp, 0.0, mdl->W, mp));     // W = C G (:167)
+  sys[0].P = G1; sys[0].ldp = mp; sys[0].m = mp; sys[0].Linv = Linv; sys[0].R = G2t; sys[0].ldr = m; sys[0].nrhs = m;
+  sys[1].P = G3; sys[1].ldp = m; sys[1].m = m; sys[1].Linv = Linv2; sys[1].R = G4t; sys[1].ldr = ldd; sys[1].nrhs = d;
+  // both systems advance in lock step (paired launches); the per-block kernels are latency bound and leave the chip
+  // mostly idle ...
+  NK_TRY(cholesky_lower_pair_async(ctx, sys, 2));
+  NK_TRY(cholesky_solve_pair(ctx, sys, 2));  // G2t <- V = inner^-1 cross^T ; G4t <- Wc = inner_rec^-1 left_rec^T
+  tr.mark("cholesky + solves issued");
+
+  // ---- ... while S = K_mm^{1/2}, S^{-1} (regressors.py:140,163) runs on the side stream (GEMM bound) --------------------
+  int it = 0;
+  double resid = 0.0;
+  {
+    SideScope side(ctx);
+    NK_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_fork, 0));
+    NK_HIP(hipEventRecord(ev[6], ctx->stream));
+    NK_TRY(sqrtm_spd(ctx, Kj, m, m, mdl->S, mdl->Sinv, &it, &resid));
+    NK_HIP(hipEventRecord(ev[7], ctx->stream));
+    NK_HIP(hipEventRecord(ctx->ev_join, ctx->stream));
+  }
+  NK_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+  NK_HIP(hipEventRecord(ev[4], ctx->stream));
+  tr.mark("sqrt done (host-synced, side stream)");
+  NK_TRY(cholesky_check_pair(ctx, sys, 2));
+
+  // ---- operator products; every product is P^T Q with P stored contraction-major (fast TN engine) -----------------------
+  const double* V1 = G2t;                       // m x m   (rows 0..m-1 of V)
+  const double* V2 = G2t + (int64_t)m * m;      // p x m
+  NK_TRY(launch_transpose(ctx, mdl->Sinv, m, Sinvt, m, m, m));
+  NK_TRY(launch_gemm(ctx, true, false, m, m, m, 1.0, Kxo, m, V1, m, 0.0, T1t, m));            // T1^T = K_xo^T V1
+  NK_TRY(launch_gemm(ctx, true, false, m, m, m, 1.0, T1t, m, mdl->Sinv, m, 0.0, X1, m));      // X1 = V1^T K_xo S^-1
+  NK_TRY(launch_gemm(ctx, true, false, m, m, m, 1.0, Sinvt, m, X1, m, 0.0, mdl->A, mp));      // A = S^-1 X1
+  if (p > 0) {
+    NK_TRY(launch_transpose(ctx, V2, m, V2t, ldv2, p, m));                                     // V2^T (m x p)
+    NK_TRY(launch_gemm(ctx, true, false, m, p, m, 1.0, Sinvt, m, V2t, ldv2, 0.0, mdl->B, mp)); // B = S^-1 V2^T
+  }
+  NK_TRY(launch_gemm(ctx, true, false, m, d, m, 1.0, mdl->S, m, G4t, ldd, 0.0, Ct, ldd));      // C^T = S^T Wc
+  NK_TRY(launch_transpose(ctx, Ct, ldd, mdl->C, m, m, d));
+  NK_TRY(launch_gemm(ctx, true, false, d, mp, m, 1.0, Ct, ldd, mdl->A, mp, 0.0, mdl->W, mp));  // W = C G (:167)
   NK_HIP(hipEventRecord(ev[5], ctx->stream));
   tr.mark("solve issued");
   NK_HIP(hipStreamSynchronize(ctx->stream));
@@ -673,8 +708,9 @@ int nk_nystrom_fit(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int64
     stats->ms_upload = (x.staged || y.staged) ? ev_ms(ctx, 0, 1) : 0.0;
     stats->ms_kmat = ev_ms(ctx, 1, 2);
     stats->ms_gram = ev_ms(ctx, 2, 3);
-    stats->ms_sqrt = ev_ms(ctx, 3, 4);
+    stats->ms_sqrt = ev_ms(ctx, 6, 7);  // on the side stream, overlapping the kernel-block and Gram stages
     stats->ms_solve = ev_ms(ctx, 4, 5);
+    if (gram_deferred) ms_gram_kernel = ev_ms(ctx, 14, 15);
     stats->ms_gram_kernel_avg = gram_launches ? ms_gram_kernel / gram_launches : 0.0;
     stats->gram_kernel_launches = gram_launches;
     stats->sqrt_iters = it;
@@ -689,7 +725,7 @@ int nk_nystrom_fit(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int64
     stats->kmat_pairs = 2.0 * ne * m * d + (same_centers ? 1.0 : 3.0) * (double)m * m * d;
   }
   tr.mark("stats");
-  if (ctx->arena.chunks.size() > 1) NK_TRY(arena_reset(ctx));  // coalesce now (everything is synchronised), not in the next call
+  if (ctx->arena.chunks.size() > 1 || ctx->arena_side.chunks.size() > 1) NK_TRY(arena_reset(ctx));  // coalesce now (everything is synchronised), not in the next call
   guard.m = nullptr;
   *model = mdl;
   return NK_OK;

@@ -56,11 +56,17 @@ struct ArenaMark {
 
 struct nk_ctx {
   int device = 0;
-  hipStream_t stream = nullptr;
-  nk::Arena arena;
+  hipStream_t stream = nullptr;       // CURRENT stream: every launcher uses this (swapped by nk::SideScope)
+  hipStream_t stream_main = nullptr;
+  hipStream_t stream_side = nullptr;  // second stream for work that is independent of the main chain
+  nk::Arena arena;                    // workspace of the main stream
+  nk::Arena arena_side;               // workspace of the side stream (slabs must not be shared across streams)
+  nk::Arena* cur_arena = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int* d_info = nullptr;       // device flags for factorisation failures (one int per paired system)
   double* d_scalars = nullptr; // small device scratch for reductions (64 doubles)
   double* h_scalars = nullptr; // pinned host mirror
+  int* h_info = nullptr;       // pinned host mirror of d_info (kept apart from h_scalars: both streams may be in flight)
   double* d_zeros = nullptr;   // 4 KiB zero page (K-tail rows of the LDS-DMA GEMM)
   hipEvent_t ev[16];
   int num_cu = 256;
@@ -81,6 +87,21 @@ struct nk_model {
 };
 
 namespace nk {
+
+// Route launches and workspace allocations to the side stream for the lifetime of the scope.
+struct SideScope {
+  nk_ctx* c;
+  hipStream_t s0;
+  Arena* a0;
+  explicit SideScope(nk_ctx* ctx) : c(ctx), s0(ctx->stream), a0(ctx->cur_arena) {
+    c->stream = c->stream_side;
+    c->cur_arena = &c->arena_side;
+  }
+  ~SideScope() {
+    c->stream = s0;
+    c->cur_arena = a0;
+  }
+};
 
 // ---- workspace -------------------------------------------------------------------------------------------
 int arena_reset(nk_ctx* ctx);
@@ -152,6 +173,8 @@ struct CholSys {
   int nrhs = 0;
 };
 int cholesky_lower_pair(nk_ctx* ctx, const CholSys* sys, int nsys);
+int cholesky_lower_pair_async(nk_ctx* ctx, const CholSys* sys, int nsys);  // no host synchronisation
+int cholesky_check_pair(nk_ctx* ctx, const CholSys* sys, int nsys);       // verdict of the async factorisation
 int cholesky_solve_pair(nk_ctx* ctx, const CholSys* sys, int nsys);
 constexpr int CHOL_NB = 64;
 
@@ -172,7 +195,7 @@ struct TnProblem {
 };
 bool tn_fast_ok(const TnProblem& p);  // alignment / leading-dimension requirements of the LDS-DMA path
 int launch_gemm_tn_multi(nk_ctx* ctx, const TnProblem* probs, int nprob, int64_t K, int splitk /*0=auto*/,
-                         float* ms_kernel = nullptr);
+                         float* ms_kernel = nullptr, bool sync_timing = true);
 int launch_transpose(nk_ctx* ctx, const double* src, int64_t lds, double* dst, int64_t ldd, int rows, int cols);
 // Gram-form kernel matrix on the MFMA engine (nk_gemm_tn.hip): prep_rows centres/scales/transposes rows to
 // contraction-major and returns their squared norms; launch_kmat_gram evaluates k() in the GEMM epilogue

@@ -314,11 +314,12 @@ static bool g_tn_attr_set = false;
 static int ensure_zero_page(nk_ctx* ctx) {
   if (ctx->d_zeros) return NK_OK;
   NK_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->d_zeros), 4096));
-  NK_HIP(hipMemsetAsync(ctx->d_zeros, 0, 4096, ctx->stream));
+  NK_HIP(hipMemset(ctx->d_zeros, 0, 4096));  // blocking: both streams of the context read this page
   return NK_OK;
 }
 
-int launch_gemm_tn_multi(nk_ctx* ctx, const TnProblem* probs, int nprob, int64_t K, int splitk, float* ms_kernel) {
+int launch_gemm_tn_multi(nk_ctx* ctx, const TnProblem* probs, int nprob, int64_t K, int splitk, float* ms_kernel,
+                         bool sync_timing) {
   NK_REQUIRE(nprob >= 1 && nprob <= TN_MAXP, "gemm_tn_multi: 1..4 problems");
   NK_REQUIRE(K >= 0 && K < (1LL << 31), "gemm_tn_multi: K out of range");
   NK_TRY(ensure_zero_page(ctx));
@@ -394,7 +395,7 @@ int launch_gemm_tn_multi(nk_ctx* ctx, const TnProblem* probs, int nprob, int64_t
     hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, R);
     NK_HIP(hipGetLastError());
   }
-  if (ms_kernel) {
+  if (ms_kernel && sync_timing) {  // otherwise the caller reads ev[14] -> ev[15] after its own synchronisation
     NK_HIP(hipEventSynchronize(ctx->ev[15]));
     NK_HIP(hipEventElapsedTime(ms_kernel, ctx->ev[14], ctx->ev[15]));
   }

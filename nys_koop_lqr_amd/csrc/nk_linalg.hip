@@ -378,7 +378,7 @@ int sqrtm_spd(nk_ctx* ctx, const double* P, int64_t ldp, int m, double* S, doubl
 int launch_potrf_diag_pair(nk_ctx* ctx, double* const* Ajj, const int64_t* lda, const int* nb, double* const* Linv,
                            int nsys, int blk);
 
-int cholesky_lower_pair(nk_ctx* ctx, const CholSys* sys, int nsys) {
+int cholesky_lower_pair_async(nk_ctx* ctx, const CholSys* sys, int nsys) {
   constexpr int NB = CHOL_NB;
   NK_REQUIRE(nsys >= 1 && nsys <= 2, "cholesky_lower_pair: 1..2 systems");
   NK_HIP(hipMemsetAsync(ctx->d_info, 0, 2 * sizeof(int), ctx->stream));
@@ -416,9 +416,14 @@ int cholesky_lower_pair(nk_ctx* ctx, const CholSys* sys, int nsys) {
     NK_TRY(launch_gemm_pair(ctx, false, true, panel, nsys));
     NK_TRY(launch_gemm_pair(ctx, false, true, trail, nsys));
   }
-  NK_HIP(hipMemcpyAsync(ctx->h_scalars, ctx->d_info, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  return NK_OK;
+}
+
+// Host-side verdict of the factorisations queued by cholesky_lower_pair_async (synchronises the current stream).
+int cholesky_check_pair(nk_ctx* ctx, const CholSys* sys, int nsys) {
+  NK_HIP(hipMemcpyAsync(ctx->h_info, ctx->d_info, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   NK_HIP(hipStreamSynchronize(ctx->stream));
-  const int* info = reinterpret_cast<const int*>(ctx->h_scalars);
+  const int* info = ctx->h_info;
   for (int q = 0; q < nsys; ++q)
     if (info[q] != 0) {
       set_error("Cholesky: non-positive pivot at index %d of %d (system %d is numerically rank deficient; the "
@@ -426,6 +431,11 @@ int cholesky_lower_pair(nk_ctx* ctx, const CholSys* sys, int nsys) {
       return NK_ERR_NOT_SPD;
     }
   return NK_OK;
+}
+
+int cholesky_lower_pair(nk_ctx* ctx, const CholSys* sys, int nsys) {
+  NK_TRY(cholesky_lower_pair_async(ctx, sys, nsys));
+  return cholesky_check_pair(ctx, sys, nsys);
 }
 
 int cholesky_solve_pair(nk_ctx* ctx, const CholSys* sys, int nsys) {
