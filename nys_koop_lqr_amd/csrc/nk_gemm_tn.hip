@@ -137,7 +137,6 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_f64_kernel(TnParams P) {
     const int st = kt & 1;
     // my DMAs for step kt have landed; after the barrier everybody's have, and everybody is done reading stage st^1
     __syncthreads();
-    if (kt + 1 < ktiles) issue(kt + 1, st ^ 1);
     const double* a_base = smem + st * TSTAGE + wm * 64 + r16;
     const double* b_base = smem + st * TSTAGE + TBK * TSTRIDE + wn * 64 + r16;
 #pragma unroll
@@ -153,6 +152,9 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_f64_kernel(TnParams P) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+      // the DMA for the next step is issued in the shadow of the first 16 MFMAs (the matrix pipe is busy for 1024
+      // cycles; address arithmetic and the 8 LDS-DMA instructions issue meanwhile)
+      if (ks == 0 && kt + 1 < ktiles) issue(kt + 1, st ^ 1);
     }
   }
 
