@@ -95,13 +95,23 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # NYSKOOP_BENCH_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks (ranks share
+    # devices round-robin, collectives on CPU tensors); the real runs use RCCL ("nccl"), one rank per GPU.
+    backend = os.environ.get("NYSKOOP_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank if backend == "nccl" else local_rank % max(ndev, 1)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(dev_index)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend=backend)
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", dev_index)
+    cdev = dev if backend == "nccl" else torch.device("cpu")  # where collective payloads live
     torch.cuda.set_device(dev)
+    local_rank = dev_index
 
     import nys_koop_lqr_amd as nk
     from nys_koop_lqr_amd import _lib
@@ -134,14 +144,14 @@ def main():
         stats.append(last.fit_stats_)
     ctx.synchronize()
     torch.cuda.synchronize()
-    diag = torch.tensor([st["sqrt_residual"] for st in stats], dtype=torch.float64, device=dev)
+    diag = torch.tensor([st["sqrt_residual"] for st in stats], dtype=torch.float64, device=cdev)
     if world > 1:
         gathered = [torch.empty_like(diag) for _ in range(world)]
         dist.all_gather(gathered, diag)  # per-fit scalars only: the one collective of the sweep
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
