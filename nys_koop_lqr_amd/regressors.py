@@ -280,3 +280,81 @@ class KoopmanNystromRegressor(KoopmanRegressor):
     @property
     def fit_stats_(self):
         return self._stats
+
+
+class KoopmanKernelRegressor(KoopmanRegressor):
+    """regressors.py:58-111: the exact (non-Nystrom) kernel estimator, lifted dimension N = #samples.  Used by the
+    reference only as the accuracy comparator of benchmark_lqr_hjb.py:334-381 (N ~ 4000).  Composed on the host from
+    the library's device building blocks (nk_kernel_matrix, nk_sqrtm_spd, nk_solve_spd, nk_gemm): every O(N^2 d) and
+    O(N^3) step runs on the GPU; the reference's pinv(sqrtm(K)) is the inverse square root the Newton-Schulz
+    iteration returns directly.
+    """
+
+    def __init__(self, n_inputs, kernel=None, gamma=None):
+        super().__init__(n_inputs, gamma)
+        self.kernel = kernel
+        self.training_inputs = None
+        self.training_outputs = None
+        self.jitter = 1e-6
+
+    @staticmethod
+    def _gemm(ctx, A, B):
+        A = np.ascontiguousarray(A, dtype=np.float64)
+        B = np.ascontiguousarray(B, dtype=np.float64)
+        out = np.empty((A.shape[0], B.shape[1]))
+        _lib.check(ctx.lib.nk_gemm(ctx.handle, 0, 0, A.shape[0], B.shape[1], A.shape[1], 1.0, A.ctypes.data, A.shape[1],
+                                   B.ctypes.data, B.shape[1], 0.0, out.ctypes.data, out.shape[1]))
+        return out
+
+    @staticmethod
+    def _solve_spd(ctx, P, R):
+        P = np.ascontiguousarray(P, dtype=np.float64)
+        R = np.ascontiguousarray(R, dtype=np.float64)
+        X = np.empty_like(R)
+        rc = ctx.lib.nk_solve_spd(ctx.handle, P.ctypes.data, P.shape[1], P.shape[0], R.ctypes.data, R.shape[1],
+                                  R.shape[1], X.ctypes.data, X.shape[1])
+        if rc == -3:
+            raise np.linalg.LinAlgError(ctx.lib.nk_last_error().decode())
+        _lib.check(rc)
+        return X
+
+    def fit(self, X, Y):
+        ctx = _lib.get_context()
+        X = np.asarray(X, dtype=np.float64).T  # (d+p) x N, as regressors.py:67-68
+        Y = np.asarray(Y, dtype=np.float64).T
+        n_states = X.shape[0] - self.n_inputs
+        N = X.shape[1]
+        gamma_n = self.gamma * N
+        if self.training_inputs is None:
+            self.training_inputs = X
+        if self.training_outputs is None:
+            self.training_outputs = Y
+        k = self.kernel.kernel
+        Xs = np.ascontiguousarray(self.training_inputs[:n_states, :].T)
+        Us = np.ascontiguousarray(self.training_inputs[n_states:, :].T)  # N x p
+        Ys = np.ascontiguousarray(self.training_outputs.T)
+        K_ins = k(Xs, Xs) + self._gemm(ctx, Us, Us.T) + gamma_n * np.eye(N)  # :82-84
+        Kout = k(Ys, Ys) + self.jitter * np.eye(N)  # :85
+        self.Kout = Kout
+        S, Sinv = np.empty((N, N)), np.empty((N, N))
+        it, res = C.c_int32(), C.c_double()
+        _lib.check(ctx.lib.nk_sqrtm_spd(ctx.handle, Kout.ctypes.data, N, N, S.ctypes.data, Sinv.ctypes.data,
+                                        C.byref(it), C.byref(res)))  # :87-88 (sqrtm, pinv)
+        self.Kout_sqrt_inv = Sinv
+        Kins_x_outs = k(Xs, Ys)  # :90
+        right_state = self._gemm(ctx, Sinv, Kins_x_outs.T).T  # :91
+        right = np.hstack((right_state, Us))  # :92
+        G_ls = self._gemm(ctx, S, self._solve_spd(ctx, K_ins, right))  # :93
+        self.A = G_ls[:, :N]
+        self.B = G_ls[:, N:]
+        # :98-99 -- Phi = (S^-1 Kout)^T; C = Y (Phi Phi^T + gamma_n I)^-1 Phi
+        Phi = self._gemm(ctx, Sinv, Kout).T
+        PPt = self._gemm(ctx, Phi, Phi.T) + gamma_n * np.eye(N)
+        self.C = self._gemm(ctx, self.training_outputs, self._solve_spd(ctx, PPt, Phi))
+        self.weights = self._gemm(ctx, self.C, G_ls)  # :100-102
+
+    def lift(self, X):
+        """regressors.py:104-111."""
+        ctx = _lib.get_context()
+        Kout_test = self.kernel.kernel(np.ascontiguousarray(self.training_outputs.T), np.ascontiguousarray(np.asarray(X).T))
+        return self._gemm(ctx, self.Kout_sqrt_inv, Kout_test)

@@ -147,6 +147,14 @@ def main():
     np.savez_compressed(f"{OUT}/f4_hjb_matern.npz", **pack_fit(
         reg, X, Y, idx, extra=dict(ls=np.array([0.1]), gamma=1e-4)))
 
+    # ---- F4c: exact kernel estimator (KoopmanKernelRegressor, regressors.py:58-111) on the first 300 HJB samples
+    Xk, Yk = X[:300], Y[:300]
+    kreg = R.KoopmanKernelRegressor(1, kernel=R.KernelWrapper([0.5]), gamma=1e-4)
+    kreg.fit(Xk, Yk)
+    qk = np.linspace(-0.9, 0.9, 7).reshape(1, -1)
+    np.savez_compressed(f"{OUT}/f4c_hjb_exact_kernel.npz", X=Xk, Y=Yk, ls=np.array([0.5]), gamma=1e-4,
+                        W=kreg.weights, C=kreg.C, lift=kreg.lift(qk), q=qk, predict=kreg.predict(Xk[:9]))
+
     # ---- F4b: linear kernel (LinearKernelWrapper, regressors.py:28-30) kernel-matrix values only
     Aq = np.random.RandomState(5).standard_normal((9, 7))
     Bq = np.random.RandomState(6).standard_normal((13, 7))

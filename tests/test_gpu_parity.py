@@ -249,6 +249,18 @@ def test_fit_with_global_rng_and_row_ranges(nk, O, golden):
         c.fit(X, Y)
 
 
+def test_exact_kernel_regressor_vs_reference_golden(nk, golden):
+    """KoopmanKernelRegressor (regressors.py:58-111), the accuracy comparator of benchmark_lqr_hjb.py:334-381, composed
+    from the device building blocks.  N x N systems with jitter 1e-6 are ill-conditioned: graded on lift / predict."""
+    g = golden("f4c_hjb_exact_kernel.npz")
+    reg = nk.KoopmanKernelRegressor(1, kernel=nk.KernelWrapper(g["ls"]), gamma=float(g["gamma"]))
+    reg.fit(g["X"], g["Y"])
+    N = g["X"].shape[0]
+    assert reg.A.shape == (N, N) and reg.B.shape == (N, 1) and reg.C.shape == (1, N) and reg.weights.shape == (1, N + 1)
+    assert relf(reg.lift(g["q"]), g["lift"]) < 1e-6
+    assert relf(reg.predict(g["X"][:9]), g["predict"]) < 1e-5
+
+
 def test_gridsearch_scores_vs_sklearn_driving_reference(nk, golden):
     from nys_koop_lqr_amd import harness
     g = golden("f5_cloth_gridsearch.npz")
