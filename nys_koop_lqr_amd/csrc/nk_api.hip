@@ -899,12 +899,21 @@ int nk_rollout(nk_ctx* ctx, const nk_model* mdl, const double* x0, int64_t ldx0,
   const int64_t ldz = (int64_t)T * m;
   NK_TRY(lift_device(ctx, mdl, x.ptr, x.ld, batch, Zall, ldz));  // z_0 = phi(x_0) for every trajectory
   for (int t = 0; t + 1 < T; ++t) {
-    // z_{t+1} = z_t A^T + u_t B^T      (benchmark_lqr_cloth.py:30)
-    NK_TRY(launch_gemm(ctx, false, true, batch, m, m, 1.0, Zall + (int64_t)t * m, ldz, mdl->A, mp, 0.0,
-                       Zall + (int64_t)(t + 1) * m, ldz));
-    if (p > 0)
-      NK_TRY(launch_gemm(ctx, false, true, batch, m, p, 1.0, u.ptr + (int64_t)t * p, u.ld, mdl->B, mp, 1.0,
+    // z_{t+1} = A z_t + B u_t      (benchmark_lqr_cloth.py:30)
+    if (batch <= 16) {  // matrix-vector chain: one wave per row of [A | B], trajectories in groups of 8
+      for (int b0 = 0; b0 < batch; b0 += 8) {
+        const int nb = batch - b0 < 8 ? batch - b0 : 8;
+        NK_TRY(launch_lifted_step(ctx, mdl->A, mp, m, m, p, Zall + (int64_t)b0 * ldz + (int64_t)t * m, ldz,
+                                  p > 0 ? u.ptr + (int64_t)b0 * u.ld + (int64_t)t * p : nullptr, u.ld, nullptr,
+                                  Zall + (int64_t)b0 * ldz + (int64_t)(t + 1) * m, ldz, nb));
+      }
+    } else {
+      NK_TRY(launch_gemm(ctx, false, true, batch, m, m, 1.0, Zall + (int64_t)t * m, ldz, mdl->A, mp, 0.0,
                          Zall + (int64_t)(t + 1) * m, ldz));
+      if (p > 0)
+        NK_TRY(launch_gemm(ctx, false, true, batch, m, p, 1.0, u.ptr + (int64_t)t * p, u.ld, mdl->B, mp, 1.0,
+                           Zall + (int64_t)(t + 1) * m, ldz));
+    }
   }
   NK_TRY(launch_gemm(ctx, false, true, (int64_t)batch * T, d, m, 1.0, Zall, m, mdl->C, m, 0.0, ox.dev, ox.ld));
   if (out_z && Zall != oz.dev) NK_TRY(launch_copy2d(ctx, Zall, m, oz.dev, oz.ld, (int64_t)batch * T, m));
@@ -927,19 +936,27 @@ int nk_closed_loop(nk_ctx* ctx, const nk_model* mdl, const double* K, const doub
   MatOut ox, ou;
   NK_TRY(stage_out(ctx, out_x, d, steps, d, &ox));
   NK_TRY(stage_out(ctx, out_u, p, steps, p, &ou));
-  double *Phi = nullptr, *diff = nullptr;
+  // phi_{t+1} = A phi_t + B K (phi_ref - phi_t) = (A - B K) phi_t + B K phi_ref: one matrix-vector step per time step
+  // (algebraically the loop of benchmark_lqr_cloth.py:79-84; the controls u_t = K (phi_ref - phi_t) are recovered for all
+  // steps at once afterwards)
+  double *Phi = nullptr, *Acl = nullptr, *kref = nullptr, *cvec = nullptr, *Dm = nullptr;
   NK_TRY(arena_alloc_t(ctx, (size_t)(steps + 1) * m, &Phi));
-  NK_TRY(arena_alloc_t(ctx, (size_t)m, &diff));
+  NK_TRY(arena_alloc_t(ctx, (size_t)m * m, &Acl));
+  NK_TRY(arena_alloc_t(ctx, (size_t)p + 8, &kref));
+  NK_TRY(arena_alloc_t(ctx, (size_t)m, &cvec));
+  NK_TRY(arena_alloc_t(ctx, (size_t)steps * m, &Dm));
   NK_TRY(launch_copy2d(ctx, f0.ptr, m, Phi, m, 1, m));
-  for (int t = 0; t < steps; ++t) {
-    double* phi = Phi + (int64_t)t * m;
-    double* ut = ou.dev + (int64_t)t * ou.ld;
-    NK_TRY(launch_copy2d(ctx, fr.ptr, m, diff, m, 1, m));
-    NK_TRY(launch_axpby2d(ctx, -1.0, phi, m, 1.0, diff, m, 1, m));                                 // phi_ref - phi
-    NK_TRY(launch_gemm(ctx, false, true, 1, p, m, 1.0, diff, m, k.ptr, k.ld, 0.0, ut, ou.ld));     // u = K (.)
-    NK_TRY(launch_gemm(ctx, false, true, 1, m, m, 1.0, phi, m, mdl->A, mp, 0.0, phi + m, m));      // A phi
-    NK_TRY(launch_gemm(ctx, false, true, 1, m, p, 1.0, ut, ou.ld, mdl->B, mp, 1.0, phi + m, m));   // + B u
-  }
+  NK_TRY(launch_copy2d(ctx, mdl->A, mp, Acl, m, m, m));
+  NK_TRY(launch_gemm(ctx, false, false, m, m, p, -1.0, mdl->B, mp, k.ptr, k.ld, 1.0, Acl, m));              // A - B K
+  NK_TRY(launch_lifted_step(ctx, k.ptr, k.ld, p, m, 0, fr.ptr, m, nullptr, 0, nullptr, kref, p, 1));        // K phi_ref
+  NK_TRY(launch_lifted_step(ctx, mdl->B, mp, m, p, 0, kref, p, nullptr, 0, nullptr, cvec, m, 1));           // B K phi_ref
+  for (int t = 0; t < steps; ++t)
+    NK_TRY(launch_lifted_step(ctx, Acl, m, m, m, 0, Phi + (int64_t)t * m, m, nullptr, 0, cvec, Phi + (int64_t)(t + 1) * m,
+                              m, 1));
+  // u_t = K (phi_ref - phi_t) for all t: D = 1 phi_ref^T - Phi, U = D K^T
+  NK_TRY(launch_copy2d(ctx, fr.ptr, 0, Dm, m, steps, m));  // row stride 0: broadcast phi_ref to every row
+  NK_TRY(launch_axpby2d(ctx, -1.0, Phi, m, 1.0, Dm, m, steps, m));
+  NK_TRY(launch_gemm(ctx, false, true, steps, p, m, 1.0, Dm, m, k.ptr, k.ld, 0.0, ou.dev, ou.ld));
   NK_TRY(launch_gemm(ctx, false, true, steps, d, m, 1.0, Phi, m, mdl->C, m, 0.0, ox.dev, ox.ld));  // x_t = C phi_t
   NK_TRY(finish_out(ctx, ox));
   NK_TRY(finish_out(ctx, ou));

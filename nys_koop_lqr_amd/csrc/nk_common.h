@@ -178,6 +178,10 @@ int cholesky_check_pair(nk_ctx* ctx, const CholSys* sys, int nsys);       // ver
 int cholesky_solve_pair(nk_ctx* ctx, const CholSys* sys, int nsys);
 constexpr int CHOL_NB = 64;
 
+// matrix-vector step of the lifted recursion for up to 8 trajectories (nk_rollout.hip)
+int launch_lifted_step(nk_ctx* ctx, const double* G, int64_t ldg, int m, int mz, int pu, const double* z, int64_t zstride,
+                       const double* u, int64_t ustride, const double* bias, double* out, int64_t ostride, int batch);
+
 }  // namespace nk
 
 namespace nk {
@@ -192,6 +196,8 @@ struct TnProblem {
   int M = 0, N = 0;
   int tri = TRI_FULL;  // TRI_UPPER_MIRROR for symmetric products (A == B)
   double alpha = 1.0, beta = 0.0;
+  double* Ct = nullptr;  // optional: also store the transpose, Ct[col][row] = C[row][col] (N x M, leading dim ldct)
+  int64_t ldct = 0;
 };
 bool tn_fast_ok(const TnProblem& p);  // alignment / leading-dimension requirements of the LDS-DMA path
 int launch_gemm_tn_multi(nk_ctx* ctx, const TnProblem* probs, int nprob, int64_t K, int splitk /*0=auto*/,

@@ -37,6 +37,8 @@ struct TnDev {
   double* C;       // direct epilogue (splitk == 1): C = alpha * acc + beta * C
   int64_t ldc;
   double alpha, beta;
+  double* Ct;      // optional transposed copy of the result
+  int64_t ldct;
 };
 struct TnParams {
   TnDev p[TN_MAXP];
@@ -174,6 +176,7 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_f64_kernel(TnParams P) {
             if (pr.beta != 0.0) v += pr.beta * pr.C[(int64_t)row * pr.ldc + col];
             pr.C[(int64_t)row * pr.ldc + col] = v;
             if (mirror) pr.C[(int64_t)col * pr.ldc + row] = v;
+            if (pr.Ct) pr.Ct[(int64_t)col * pr.ldct + row] = v;
           }
         }
   } else if (EPI == 0) {
@@ -230,7 +233,8 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_f64_kernel(TnParams P) {
 
 struct TnRed {
   double* C;
-  int64_t ldc;
+  double* Ct;
+  int64_t ldc, ldct;
   int M, N, tiles_n, tri, tile_begin;
   double alpha, beta;
 };
@@ -276,6 +280,7 @@ __global__ void __launch_bounds__(256) gemm_tn_reduce_kernel(TnRedParams P) {
     if (pr.beta != 0.0) v += pr.beta * pr.C[(int64_t)row * pr.ldc + col];
     pr.C[(int64_t)row * pr.ldc + col] = v;
     if (mirror) pr.C[(int64_t)col * pr.ldc + row] = v;
+    if (pr.Ct) pr.Ct[(int64_t)col * pr.ldct + row] = v;
   }
 }
 
@@ -336,8 +341,9 @@ int launch_gemm_tn_multi(nk_ctx* ctx, const TnProblem* probs, int nprob, int64_t
     TnDev& d = P.p[q];
     d.A = s.A; d.B = s.B; d.lda = s.lda; d.ldb = s.ldb; d.M = s.M; d.N = s.N;
     d.tiles_n = tnn; d.tri = s.tri; d.tile_begin = ntiles;
-    d.C = s.C; d.ldc = s.ldc; d.alpha = s.alpha; d.beta = s.beta;
+    d.C = s.C; d.ldc = s.ldc; d.alpha = s.alpha; d.beta = s.beta; d.Ct = s.Ct; d.ldct = s.ldct;
     TnRed& r = R.p[q];
+    r.Ct = s.Ct; r.ldct = s.ldct;
     r.C = s.C; r.ldc = s.ldc; r.M = s.M; r.N = s.N; r.tiles_n = tnn; r.tri = s.tri; r.tile_begin = ntiles;
     r.alpha = s.alpha; r.beta = s.beta;
     ntiles += s.tri == TRI_FULL ? tmn * tnn : tmn * (tmn + 1) / 2;
@@ -495,7 +501,7 @@ int launch_kmat_gram(nk_ctx* ctx, int ktype, const double* At, int64_t ldat, con
   TnDev& dv = P.p[0];
   dv.A = At; dv.B = Bt; dv.lda = ldat; dv.ldb = ldbt; dv.M = (int)nA; dv.N = (int)nB; dv.tiles_n = tnn; dv.tri = TRI_FULL;
   dv.tile_begin = 0;
-  dv.C = nullptr; dv.ldc = 0; dv.alpha = 1.0; dv.beta = 0.0;
+  dv.C = nullptr; dv.ldc = 0; dv.alpha = 1.0; dv.beta = 0.0; dv.Ct = nullptr; dv.ldct = 0;
   for (int q = 1; q < TN_MAXP; ++q) { P.p[q] = P.p[0]; P.p[q].tile_begin = 1 << 30; }
   P.nprob = 1; P.ntiles = tmn * tnn; P.K = d; P.splitk = 1;
   P.klen = ((d + TBK - 1) / TBK) * TBK;

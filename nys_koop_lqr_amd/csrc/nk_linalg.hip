@@ -263,14 +263,18 @@ static int read_scalar(nk_ctx* ctx, const double* d_ptr, double* out) {
 int sqrtm_spd(nk_ctx* ctx, const double* P, int64_t ldp, int m, double* S, double* Sinv, int* iters, double* resid) {
   const ArenaMark mk = arena_mark(ctx);
   const size_t mm = (size_t)m * m;
-  double *Y = nullptr, *Z = nullptr, *Yn = nullptr, *Zn = nullptr, *M = nullptr, *T = nullptr, *Xt = nullptr;
+  double *Y = nullptr, *Z = nullptr, *Yn = nullptr, *Zn = nullptr, *M = nullptr, *T = nullptr;
+  double *Yt = nullptr, *Zt = nullptr, *Ytn = nullptr, *Ztn = nullptr;  // transposes, written by the GEMM epilogues
   NK_TRY(arena_alloc_t(ctx, mm, &Y));
   NK_TRY(arena_alloc_t(ctx, mm, &Z));
   NK_TRY(arena_alloc_t(ctx, mm, &Yn));
   NK_TRY(arena_alloc_t(ctx, mm, &Zn));
   NK_TRY(arena_alloc_t(ctx, mm, &M));
   NK_TRY(arena_alloc_t(ctx, mm, &T));
-  NK_TRY(arena_alloc_t(ctx, mm, &Xt));
+  NK_TRY(arena_alloc_t(ctx, mm, &Yt));
+  NK_TRY(arena_alloc_t(ctx, mm, &Zt));
+  NK_TRY(arena_alloc_t(ctx, mm, &Ytn));
+  NK_TRY(arena_alloc_t(ctx, mm, &Ztn));
   double c = 0.0;
   NK_TRY(launch_max_abs_rowsum(ctx, P, ldp, m, ctx->d_scalars));
   NK_TRY(read_scalar(ctx, ctx->d_scalars, &c));
@@ -282,6 +286,8 @@ int sqrtm_spd(nk_ctx* ctx, const double* P, int64_t ldp, int m, double* S, doubl
   NK_TRY(launch_axpby2d(ctx, 1.0 / c, P, ldp, 0.0, Y, m, m, m));
   NK_TRY(launch_fill(ctx, Z, m, m, m, 0.0));
   NK_TRY(launch_add_diag(ctx, Z, m, m, 1.0));
+  NK_TRY(launch_transpose(ctx, Y, m, Yt, m, m, m));  // Y_0 = P / c (P symmetric only up to the caller's rounding)
+  NK_TRY(launch_copy2d(ctx, Z, m, Zt, m, m, m));     // Z_0 = I
   // spectrum interval [a, b] of M_0 = Y_0: b = 1 (c = ||P||_inf bounds the largest eigenvalue); a = mean of the
   // eigenvalues other than the dominant one, from trace and Frobenius norm -- an OVER-estimate of the smallest
   // eigenvalue, which is the safe side: the scaled steps stay inside (0, 3) for every eigenvalue <= b, eigenvalues
@@ -315,20 +321,24 @@ int sqrtm_spd(nk_ctx* ctx, const double* P, int64_t ldp, int m, double* S, doubl
   bool ok = false;
   for (; it < maxit; ++it) {
     // every product is issued as P^T Q with P stored contraction-major (fast LDS-DMA engine); Z and Y are only
-    // symmetric up to rounding and must NOT be replaced by their transposes (that variant diverges), so the left
-    // factors are transposed explicitly (32 MB round trip, ~15 us)
-    NK_TRY(launch_transpose(ctx, Z, m, Xt, m, m, m));
-    NK_TRY(launch_gemm(ctx, true, false, m, m, m, 1.0, Xt, m, Y, m, 0.0, M, m, sym));
-    NK_TRY(launch_frob_minus_identity(ctx, M, m, m, ctx->d_scalars));
-    double r2 = 0.0;
-    NK_TRY(read_scalar(ctx, ctx->d_scalars, &r2));
-    r_prev = r;
-    r = std::sqrt(r2 / m);
-    if (!std::isfinite(r)) break;
-    // quadratic convergence: once the previous residual was below 1e-7 this iterate sits on the rounding floor
-    if (r < 5e-14 || r_prev < 1e-7) {
-      ok = true;
-      break;
+    // symmetric up to rounding and must NOT be replaced by their transposes (that variant diverges), so true
+    // transposes are kept alongside (written by the epilogue of the launch that produces Y and Z)
+    NK_TRY(launch_gemm(ctx, true, false, m, m, m, 1.0, Zt, m, Y, m, 0.0, M, m, sym));
+    // a_lo over-estimates the smallest eigenvalue of M: while it is below 1/2 the iteration cannot have converged
+    // (||M - I||_F / sqrt(m) >= (1 - lambda_min) / sqrt(m)), so the residual reduction and its host round trip are
+    // skipped during the growth phase
+    if (a_lo >= 0.5 || it + 1 == maxit) {
+      NK_TRY(launch_frob_minus_identity(ctx, M, m, m, ctx->d_scalars));
+      double r2 = 0.0;
+      NK_TRY(read_scalar(ctx, ctx->d_scalars, &r2));
+      r_prev = r;
+      r = std::sqrt(r2 / m);
+      if (!std::isfinite(r)) break;
+      // quadratic convergence: once the previous residual was below 1e-7 this iterate sits on the rounding floor
+      if (r < 5e-14 || r_prev < 1e-7) {
+        ok = true;
+        break;
+      }
     }
     // scaled step: T = s (3I - s^2 M)/2 with s^2 = 3/(a + sqrt(ab) + b), which equalises p(s^2 a) = p(s^2 b) for
     // p(x) = x (3-x)^2 / 4, the map the step applies to the eigenvalues of M; s -> 1 as a -> b = 1
@@ -341,21 +351,26 @@ int sqrtm_spd(nk_ctx* ctx, const double* P, int64_t ldp, int m, double* S, doubl
       a_lo = lo < b_hi ? lo : b_hi;
     }
     NK_TRY(launch_scale_add_identity(ctx, -0.5 * s2 * sc, M, m, 1.5 * sc, T, m, m));
-    NK_TRY(launch_transpose(ctx, Y, m, Xt, m, m, m));
     {
       // Y T and T Z (T is exactly symmetric) share K = m: one fused launch, 2 x 256 tiles = two workgroups per CU
       TnProblem pr[2];
-      pr[0].A = Xt; pr[0].B = T; pr[0].C = Yn; pr[0].lda = pr[0].ldb = pr[0].ldc = m; pr[0].M = pr[0].N = m;
+      pr[0].A = Yt; pr[0].B = T; pr[0].C = Yn; pr[0].lda = pr[0].ldb = pr[0].ldc = m; pr[0].M = pr[0].N = m;
+      pr[0].Ct = Ytn; pr[0].ldct = m;
       pr[1].A = T; pr[1].B = Z; pr[1].C = Zn; pr[1].lda = pr[1].ldb = pr[1].ldc = m; pr[1].M = pr[1].N = m;
+      pr[1].Ct = Ztn; pr[1].ldct = m;
       if (tn_fast_ok(pr[0]) && tn_fast_ok(pr[1]) && m >= 128) {
         NK_TRY(launch_gemm_tn_multi(ctx, pr, 2, m, 0));
       } else {
-        NK_TRY(launch_gemm(ctx, true, false, m, m, m, 1.0, Xt, m, T, m, 0.0, Yn, m));
+        NK_TRY(launch_gemm(ctx, true, false, m, m, m, 1.0, Yt, m, T, m, 0.0, Yn, m));
         NK_TRY(launch_gemm(ctx, true, false, m, m, m, 1.0, T, m, Z, m, 0.0, Zn, m));
+        NK_TRY(launch_transpose(ctx, Yn, m, Ytn, m, m, m));
+        NK_TRY(launch_transpose(ctx, Zn, m, Ztn, m, m, m));
       }
     }
     double* t = Y; Y = Yn; Yn = t;
     t = Z; Z = Zn; Zn = t;
+    t = Yt; Yt = Ytn; Ytn = t;
+    t = Zt; Zt = Ztn; Ztn = t;
   }
   if (iters) *iters = it;
   if (resid) *resid = r;
