@@ -142,6 +142,9 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_f64_kernel(GemmBatch bat
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const GemmParams& p = batch.p[blockIdx.y];  // blockIdx.y selects the problem of a batched launch
   if ((int)blockIdx.x >= p.nblocks) return;
+  // small launches of this engine sit on latency-bound chains (blocked factorisation / substitution) that may share CUs
+  // with the GEMM-bound side stream: issue ahead of co-resident waves
+  if (gridDim.x <= 64) __builtin_amdgcn_s_setprio(2);
   double* As = smem;                          // [2][BK][LDS_STRIDE]
   double* Bs = smem + 2 * BK * LDS_STRIDE;    // [2][BK][LDS_STRIDE]
 

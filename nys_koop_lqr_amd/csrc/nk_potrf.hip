@@ -29,6 +29,9 @@ __global__ void __launch_bounds__(64) potrf_diag_kernel(PotrfBatch pb, int blk) 
   const int which = blockIdx.x;  // one wave per system of a paired factorisation
   const int nb = pb.nb[which];
   if (nb <= 0) return;
+  // this wave is the critical path of the factorisation chain and may share its CU with GEMM waves of the side
+  // stream: take the issue slots first
+  __builtin_amdgcn_s_setprio(3);
   double* __restrict__ A = pb.A[which];
   const int64_t lda = pb.lda[which];
   double* __restrict__ Linv = pb.Linv[which];
@@ -38,10 +41,13 @@ __global__ void __launch_bounds__(64) potrf_diag_kernel(PotrfBatch pb, int blk) 
   __shared__ double dinv[NB];
   const int lane = threadIdx.x;
   double R[NB];
+  // whole rows are loaded (the upper triangle is never consumed below: column k is only read from lanes >= k), which
+  // keeps the load free of per-element lane masks; rows / columns beyond nb are identity padding
+  const bool row_ok = lane < nb;
 #pragma unroll
   for (int j = 0; j < NB; ++j) {
     double v = (j == lane) ? 1.0 : 0.0;
-    if (lane < nb && j < nb) v = (j <= lane) ? A[(int64_t)lane * lda + j] : 0.0;
+    if (row_ok && j < nb) v = A[(int64_t)lane * lda + j];
     R[j] = v;
   }
 #pragma unroll
@@ -54,18 +60,26 @@ __global__ void __launch_bounds__(64) potrf_diag_kernel(PotrfBatch pb, int blk) 
     const double s = sqrt(dkk);
     const double inv = 1.0 / s;
     R[k] = (lane == k) ? s : R[k] * inv;  // lanes > k: L[i][k]; lanes < k hold unused upper-triangle values
+    // R[j] -= L[i][k] * L[j][k]: L[j][k] is lane j's R[k].  readlane -> SGPR pair -> scalar operand of the FMA, kept in
+    // ONE asm statement per j: left to itself hipcc hoists all 63-k readlanes ahead of the FMAs and spills them
+    // through v_writelane (3200 SGPR spills, 82 us per block).
+    {
+      const int rk_lo = __double2loint(R[k]), rk_hi = __double2hiint(R[k]);
 #pragma unroll
-    for (int j = k + 1; j < NB; ++j) {
-      const double ljk = readlane_f64(R[k], j);
-      R[j] = fma(-R[k], ljk, R[j]);
-      if ((j & 7) == 7) __builtin_amdgcn_sched_barrier(0);  // keep the readlane results from piling up in SGPRs
+      for (int j = k + 1; j < NB; ++j)
+        asm volatile("v_readlane_b32 s96, %1, %3\n\tv_readlane_b32 s97, %2, %3\n\ts_nop 0\n\tv_fma_f64 %0, -%4, s[96:97], %0"
+                     : "+v"(R[j])
+                     : "v"(rk_lo), "v"(rk_hi), "i"(j), "v"(R[k])
+                     : "s96", "s97");
     }
   }
   // L -> LDS and global (lower triangle)
+  // rows go back whole as well: nothing reads the upper triangle of a factored diagonal block (the solves use Linv,
+  // the trailing updates the panels below)
 #pragma unroll
   for (int j = 0; j < NB; ++j) {
-    Ls[lane * (NB + 1) + j] = (j <= lane) ? R[j] : 0.0;
-    if (lane < nb && j <= lane && j < nb) A[(int64_t)lane * lda + j] = R[j];
+    Ls[lane * (NB + 1) + j] = R[j];
+    if (row_ok && j < nb) A[(int64_t)lane * lda + j] = R[j];
   }
   __syncthreads();
   dinv[lane] = 1.0 / Ls[lane * (NB + 1) + lane];
