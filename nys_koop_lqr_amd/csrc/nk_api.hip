@@ -522,20 +522,44 @@ int nk_nystrom_fit(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int64
     NK_TRY(launch_add_diag(ctx, Kj_in, m, m, jitter));
     NK_TRY(launch_kmat(ctx, kd->type, zi.ptr, zi.ld, m, zo.ptr, zo.ld, m, d, mdl->winv, kd->sigma0, Kxo, m));
   }
-  // ---- feature matrix F = [K_nm_in | U | (pad) | K_nm_out], sample-major (regressors.py:141-142,147) ------------
+  // ---- feature matrix F = [K_nm_in | U | (pad) | K_nm_out], sample-major (regressors.py:141-142,147), built and
+  //      contracted in PASSES of at most `pass_rows` rows so that the workspace stays bounded for very large n (the
+  //      Gram accumulators are updated with beta = 1 from the second pass on); C4 (3.2 GB) is a single pass.
   const int64_t off_out = (mp + 1) & ~1;
   const int64_t ldf = (off_out + m + 1) & ~(int64_t)1;
+  int64_t pass_rows;
+  {
+    const char* b = getenv("NYSKOOP_F_BUDGET_GB");
+    const double budget = (b ? atof(b) : 48.0) * 1073741824.0;
+    pass_rows = (int64_t)(budget / ((double)ldf * 8.0));
+    if (pass_rows < 1024) pass_rows = 1024;
+  }
+  struct Piece { int64_t b, len; };
+  std::vector<std::vector<Piece>> passes(1);
+  {
+    int64_t used = 0;
+    for (size_t i = 0; i < rng.size(); i += 2) {
+      int64_t b = rng[i];
+      const int64_t e = rng[i + 1];
+      while (b < e) {
+        if (used == pass_rows) { passes.emplace_back(); used = 0; }
+        const int64_t len = std::min(e - b, pass_rows - used);
+        passes.back().push_back(Piece{b, len});
+        used += len;
+        b += len;
+      }
+    }
+  }
+  const int64_t f_rows = passes.size() > 1 ? pass_rows : n_eff;
   double* F = nullptr;
-  NK_TRY(arena_alloc_t(ctx, (size_t)n_eff * ldf, &F));
-  int64_t o = 0;
+  NK_TRY(arena_alloc_t(ctx, (size_t)f_rows * ldf + 64, &F));
   const bool gram_form = ctx->kmat_mode == 0 && d >= 32;
+  // Gram-form kernel blocks (MFMA engine): rows centred on the landmark mean, scaled by 1/l, transposed
+  int64_t maxlen = 0;
+  for (auto& ps : passes) for (auto& pc : ps) maxlen = std::max(maxlen, pc.len);
+  const int64_t ldt = (maxlen + 1) & ~(int64_t)1, ldzt = (m + 1) & ~1;
+  double *center = nullptr, *Rt = nullptr, *sqr = nullptr, *Zto = nullptr, *sqzo = nullptr, *Zti = nullptr, *sqzi = nullptr;
   if (gram_form) {
-    // K_nm blocks in Gram form on the MFMA engine: rows centred on the landmark mean, scaled by 1/l, transposed
-    const ArenaMark mk = arena_mark(ctx);
-    int64_t maxlen = 0;
-    for (size_t i = 0; i < rng.size(); i += 2) maxlen = std::max<int64_t>(maxlen, rng[i + 1] - rng[i]);
-    const int64_t ldt = (maxlen + 1) & ~(int64_t)1, ldzt = (m + 1) & ~1;
-    double *center = nullptr, *Rt = nullptr, *sqr = nullptr, *Zto = nullptr, *sqzo = nullptr, *Zti = nullptr, *sqzi = nullptr;
     NK_TRY(arena_alloc_t(ctx, (size_t)d, &center));
     NK_TRY(arena_alloc_t(ctx, (size_t)d * ldt, &Rt));
     NK_TRY(arena_alloc_t(ctx, (size_t)maxlen, &sqr));
@@ -550,32 +574,8 @@ int nk_nystrom_fit(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int64
       NK_TRY(arena_alloc_t(ctx, (size_t)m, &sqzi));
       NK_TRY(prep_rows(ctx, zi.ptr, zi.ld, m, d, mdl->winv, center, Zti, ldzt, sqzi));
     }
-    for (size_t i = 0; i < rng.size(); i += 2) {
-      const int64_t b = rng[i], len = rng[i + 1] - rng[i];
-      NK_TRY(prep_rows(ctx, x.ptr + b * x.ld, x.ld, len, d, mdl->winv, center, Rt, ldt, sqr));
-      NK_TRY(launch_kmat_gram(ctx, kd->type, Rt, ldt, sqr, len, Zti, ldzt, sqzi, m, d, kd->sigma0, F + o * ldf, ldf));
-      if (p > 0) NK_TRY(launch_copy2d(ctx, x.ptr + b * x.ld + d, x.ld, F + o * ldf + m, ldf, len, p));
-      NK_TRY(prep_rows(ctx, y.ptr + b * y.ld, y.ld, len, d, mdl->winv, center, Rt, ldt, sqr));
-      NK_TRY(launch_kmat_gram(ctx, kd->type, Rt, ldt, sqr, len, Zto, ldzt, sqzo, m, d, kd->sigma0, F + o * ldf + off_out,
-                              ldf));
-      o += len;
-    }
-    arena_release(ctx, mk);
-  } else {
-    for (size_t i = 0; i < rng.size(); i += 2) {
-      const int64_t b = rng[i], len = rng[i + 1] - rng[i];
-      NK_TRY(launch_kmat(ctx, kd->type, x.ptr + b * x.ld, x.ld, len, zi.ptr, zi.ld, m, d, mdl->winv, kd->sigma0,
-                         F + o * ldf, ldf));
-      if (p > 0) NK_TRY(launch_copy2d(ctx, x.ptr + b * x.ld + d, x.ld, F + o * ldf + m, ldf, len, p));
-      NK_TRY(launch_kmat(ctx, kd->type, y.ptr + b * y.ld, y.ld, len, zo.ptr, zo.ld, m, d, mdl->winv, kd->sigma0,
-                         F + o * ldf + off_out, ldf));
-      o += len;
-    }
   }
-  NK_HIP(hipEventRecord(ev[2], ctx->stream));
-  tr.mark("kmat issued");
-
-  // ---- Gram contractions over the samples (regressors.py:151,153,162,164): ONE fused launch ------------------------
+  // Gram accumulators (regressors.py:151,153,162,164):
   //   G1 = Phi_in^T Phi_in (symmetric), G2t = Phi_in^T Phi_out (= cross^T), G3 = Phi_out^T Phi_out (symmetric),
   //   G4t = Phi_out^T Y (= left_rec^T)
   double *G1 = nullptr, *G2t = nullptr, *G3 = nullptr, *G4t = nullptr;
@@ -588,7 +588,35 @@ int nk_nystrom_fit(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int64
   int gram_launches = 0;
   bool gram_deferred = false;
   const bool timed = stats != nullptr;
-  {
+  const bool multi_pass = passes.size() > 1;
+  for (size_t ip = 0; ip < passes.size(); ++ip) {
+    const std::vector<Piece>& ps = passes[ip];
+    const double beta = ip == 0 ? 0.0 : 1.0;
+    // -- kernel blocks of this pass
+    int64_t o = 0;
+    for (const Piece& pc : ps) {
+      const double* xs = x.ptr + pc.b * x.ld;
+      const double* ys = y.ptr + pc.b * y.ld;
+      if (gram_form) {
+        NK_TRY(prep_rows(ctx, xs, x.ld, pc.len, d, mdl->winv, center, Rt, ldt, sqr));
+        NK_TRY(launch_kmat_gram(ctx, kd->type, Rt, ldt, sqr, pc.len, Zti, ldzt, sqzi, m, d, kd->sigma0, F + o * ldf, ldf));
+        NK_TRY(prep_rows(ctx, ys, y.ld, pc.len, d, mdl->winv, center, Rt, ldt, sqr));
+        NK_TRY(launch_kmat_gram(ctx, kd->type, Rt, ldt, sqr, pc.len, Zto, ldzt, sqzo, m, d, kd->sigma0,
+                                F + o * ldf + off_out, ldf));
+      } else {
+        NK_TRY(launch_kmat(ctx, kd->type, xs, x.ld, pc.len, zi.ptr, zi.ld, m, d, mdl->winv, kd->sigma0, F + o * ldf, ldf));
+        NK_TRY(launch_kmat(ctx, kd->type, ys, y.ld, pc.len, zo.ptr, zo.ld, m, d, mdl->winv, kd->sigma0,
+                           F + o * ldf + off_out, ldf));
+      }
+      if (p > 0) NK_TRY(launch_copy2d(ctx, xs + d, x.ld, F + o * ldf + m, ldf, pc.len, p));
+      o += pc.len;
+    }
+    const int64_t rows = o;
+    if (ip == 0) {
+      NK_HIP(hipEventRecord(ev[2], ctx->stream));
+      tr.mark("kmat issued");
+    }
+    // -- contraction of this pass: ONE fused launch when the operands meet the LDS-DMA alignment contract
     TnProblem pr[4];
     pr[0].A = F; pr[0].B = F; pr[0].lda = pr[0].ldb = ldf; pr[0].M = pr[0].N = mp; pr[0].C = G1; pr[0].ldc = mp;
     pr[0].tri = TRI_UPPER_MIRROR;
@@ -597,41 +625,39 @@ int nk_nystrom_fit(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int64
     pr[2].A = F + off_out; pr[2].B = F + off_out; pr[2].lda = pr[2].ldb = ldf; pr[2].M = pr[2].N = m; pr[2].C = G3;
     pr[2].ldc = m; pr[2].tri = TRI_UPPER_MIRROR;
     pr[3].A = F + off_out; pr[3].lda = ldf; pr[3].M = m; pr[3].N = d; pr[3].C = G4t; pr[3].ldc = ldd;
-    pr[3].B = y.ptr + rng[0] * y.ld; pr[3].ldb = y.ld;
-    const bool single = rng.size() == 2;
-    bool fast = tn_fast_ok(pr[0]) && tn_fast_ok(pr[1]) && tn_fast_ok(pr[2]);
+    pr[3].B = y.ptr + ps[0].b * y.ld; pr[3].ldb = y.ld;
+    for (int q = 0; q < 4; ++q) pr[q].beta = beta;
+    const bool single = ps.size() == 1;
+    const bool fast = tn_fast_ok(pr[0]) && tn_fast_ok(pr[1]) && tn_fast_ok(pr[2]);
     const bool fast_y = fast && tn_fast_ok(pr[3]);
+    bool y_done = false;
     if (fast) {
       const int np = (single && fast_y) ? 4 : 3;
-      NK_TRY(launch_gemm_tn_multi(ctx, pr, np, n_eff, 0, timed ? &ms_gram_kernel : nullptr, false));
-      gram_deferred = timed;
-      gram_launches = 1;
-      if (np == 3) {
-        int64_t oo = 0;
-        for (size_t i = 0; i < rng.size(); i += 2) {
-          const int64_t b = rng[i], len = rng[i + 1] - rng[i];
-          NK_TRY(launch_gemm(ctx, true, false, m, d, len, 1.0, F + oo * ldf + off_out, ldf, y.ptr + b * y.ld, y.ld,
-                             i == 0 ? 0.0 : 1.0, G4t, ldd));
-          oo += len;
-        }
-      }
+      float ms1 = 0.f;
+      NK_TRY(launch_gemm_tn_multi(ctx, pr, np, rows, 0, timed ? &ms1 : nullptr, multi_pass));
+      if (multi_pass) ms_gram_kernel += ms1; else gram_deferred = timed;
+      gram_launches += 1;
+      y_done = np == 4;
     } else {  // unaligned operands (odd m+p): generic engine
       GemmOpts sym;
       sym.tri = TRI_UPPER_MIRROR;
       float t3[3] = {0.f, 0.f, 0.f};
-      NK_TRY(launch_gemm(ctx, true, false, mp, mp, n_eff, 1.0, F, ldf, F, ldf, 0.0, G1, mp, sym, timed ? &t3[0] : nullptr));
-      NK_TRY(launch_gemm(ctx, true, false, mp, m, n_eff, 1.0, F, ldf, F + off_out, ldf, 0.0, G2t, m, GemmOpts(),
+      NK_TRY(launch_gemm(ctx, true, false, mp, mp, rows, 1.0, F, ldf, F, ldf, beta, G1, mp, sym, timed ? &t3[0] : nullptr));
+      NK_TRY(launch_gemm(ctx, true, false, mp, m, rows, 1.0, F, ldf, F + off_out, ldf, beta, G2t, m, GemmOpts(),
                          timed ? &t3[1] : nullptr));
-      NK_TRY(launch_gemm(ctx, true, false, m, m, n_eff, 1.0, F + off_out, ldf, F + off_out, ldf, 0.0, G3, m, sym,
+      NK_TRY(launch_gemm(ctx, true, false, m, m, rows, 1.0, F + off_out, ldf, F + off_out, ldf, beta, G3, m, sym,
                          timed ? &t3[2] : nullptr));
-      ms_gram_kernel = t3[0] + t3[1] + t3[2];
-      gram_launches = 3;
+      ms_gram_kernel += t3[0] + t3[1] + t3[2];
+      gram_launches += 3;
+    }
+    if (!y_done) {
       int64_t oo = 0;
-      for (size_t i = 0; i < rng.size(); i += 2) {
-        const int64_t b = rng[i], len = rng[i + 1] - rng[i];
-        NK_TRY(launch_gemm(ctx, true, false, m, d, len, 1.0, F + oo * ldf + off_out, ldf, y.ptr + b * y.ld, y.ld,
-                           i == 0 ? 0.0 : 1.0, G4t, ldd));
-        oo += len;
+      bool first = true;
+      for (const Piece& pc : ps) {
+        NK_TRY(launch_gemm(ctx, true, false, m, d, pc.len, 1.0, F + oo * ldf + off_out, ldf, y.ptr + pc.b * y.ld, y.ld,
+                           (first && ip == 0) ? 0.0 : 1.0, G4t, ldd));
+        oo += pc.len;
+        first = false;
       }
     }
   }

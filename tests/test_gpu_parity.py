@@ -261,6 +261,33 @@ def test_exact_kernel_regressor_vs_reference_golden(nk, golden):
     assert relf(reg.predict(g["X"][:9]), g["predict"]) < 1e-5
 
 
+def test_multi_pass_accumulation_matches_single_pass(nk, monkeypatch):
+    """Very large n is contracted in row passes with the Gram accumulators updated in place (beta = 1): a tiny workspace
+    budget forces 3 passes (+ a K-fold style pair of row ranges) and must reproduce the single-pass operators."""
+    rng = np.random.default_rng(5)
+    n, d, p, m = 3000, 40, 2, 64
+    S = rng.standard_normal((n, d))
+    U = rng.standard_normal((n, p))
+    Y = np.tanh(S @ (rng.standard_normal((d, d)) * 0.9 / np.sqrt(d))) + U @ (rng.standard_normal((p, d)) * 0.1)
+    X = np.hstack([S, U])
+    idx = rng.choice(n, m, replace=False)
+
+    def fit(ranges=None):
+        reg = nk.KoopmanNystromRegressor(p, kernel=nk.ThreeDimensionalKernel(4.0, 5.0, 6.0, d), gamma=1e-4, m=m)
+        reg.nystrom_centers_output = Y.T[:, idx]
+        reg.fit(X, Y, row_ranges=ranges)
+        return reg
+
+    one = fit()
+    one_r = fit([(0, 1000), (1500, 3000)])
+    monkeypatch.setenv("NYSKOOP_F_BUDGET_GB", "1e-6")  # -> the 1024-row minimum per pass
+    many = fit()
+    many_r = fit([(0, 1000), (1500, 3000)])
+    assert many.fit_stats_["gram_kernel_launches"] >= 3 and one.fit_stats_["gram_kernel_launches"] == 1
+    assert relf(many.A, one.A) < 1e-9 and relf(many.C, one.C) < 1e-9 and relf(many.weights, one.weights) < 1e-9
+    assert relf(many_r.A, one_r.A) < 1e-9 and relf(many_r.weights, one_r.weights) < 1e-9
+
+
 def test_gridsearch_scores_vs_sklearn_driving_reference(nk, golden):
     from nys_koop_lqr_amd import harness
     g = golden("f5_cloth_gridsearch.npz")
