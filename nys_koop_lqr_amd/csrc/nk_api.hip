@@ -576,14 +576,15 @@ int nk_nystrom_fit(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int64
     }
   }
   // Gram accumulators (regressors.py:151,153,162,164):
-  //   G1 = Phi_in^T Phi_in (symmetric), G2t = Phi_in^T Phi_out (= cross^T), G3 = Phi_out^T Phi_out (symmetric),
-  //   G4t = Phi_out^T Y (= left_rec^T)
-  double *G1 = nullptr, *G2t = nullptr, *G3 = nullptr, *G4t = nullptr;
+  //   G1 = Phi_in^T Phi_in (symmetric), G2 = Phi_out^T Phi_in (= cross), G3 = Phi_out^T Phi_out (symmetric),
+  //   G4 = Y^T Phi_out (= left_rec).  G2 sits directly below G1 and G4 below G3: the right-hand sides of the two
+  //   regularised systems ride along the blocked factorisations as extra rows (cholesky_aug_pair_async).
+  double *G1 = nullptr, *G2 = nullptr, *G3 = nullptr, *G4 = nullptr;
   const int64_t ldd = d + (d & 1);
-  NK_TRY(arena_alloc_t(ctx, (size_t)mp * mp, &G1));
-  NK_TRY(arena_alloc_t(ctx, (size_t)mp * m, &G2t));
-  NK_TRY(arena_alloc_t(ctx, (size_t)m * m, &G3));
-  NK_TRY(arena_alloc_t(ctx, (size_t)m * ldd, &G4t));
+  NK_TRY(arena_alloc_t(ctx, (size_t)(mp + m) * mp, &G1));
+  G2 = G1 + (size_t)mp * mp;
+  NK_TRY(arena_alloc_t(ctx, (size_t)(m + d) * m, &G3));
+  G4 = G3 + (size_t)m * m;
   float ms_gram_kernel = 0.f;
   int gram_launches = 0;
   bool gram_deferred = false;
@@ -620,12 +621,12 @@ int nk_nystrom_fit(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int64
     TnProblem pr[4];
     pr[0].A = F; pr[0].B = F; pr[0].lda = pr[0].ldb = ldf; pr[0].M = pr[0].N = mp; pr[0].C = G1; pr[0].ldc = mp;
     pr[0].tri = TRI_UPPER_MIRROR;
-    pr[1].A = F; pr[1].B = F + off_out; pr[1].lda = pr[1].ldb = ldf; pr[1].M = mp; pr[1].N = m; pr[1].C = G2t;
-    pr[1].ldc = m;
+    pr[1].A = F + off_out; pr[1].B = F; pr[1].lda = pr[1].ldb = ldf; pr[1].M = m; pr[1].N = mp; pr[1].C = G2;
+    pr[1].ldc = mp;
     pr[2].A = F + off_out; pr[2].B = F + off_out; pr[2].lda = pr[2].ldb = ldf; pr[2].M = pr[2].N = m; pr[2].C = G3;
     pr[2].ldc = m; pr[2].tri = TRI_UPPER_MIRROR;
-    pr[3].A = F + off_out; pr[3].lda = ldf; pr[3].M = m; pr[3].N = d; pr[3].C = G4t; pr[3].ldc = ldd;
-    pr[3].B = y.ptr + ps[0].b * y.ld; pr[3].ldb = y.ld;
+    pr[3].A = y.ptr + ps[0].b * y.ld; pr[3].lda = y.ld; pr[3].M = d; pr[3].N = m; pr[3].C = G4; pr[3].ldc = m;
+    pr[3].B = F + off_out; pr[3].ldb = ldf;
     for (int q = 0; q < 4; ++q) pr[q].beta = beta;
     const bool single = ps.size() == 1;
     const bool fast = tn_fast_ok(pr[0]) && tn_fast_ok(pr[1]) && tn_fast_ok(pr[2]);
@@ -643,7 +644,7 @@ int nk_nystrom_fit(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int64
       sym.tri = TRI_UPPER_MIRROR;
       float t3[3] = {0.f, 0.f, 0.f};
       NK_TRY(launch_gemm(ctx, true, false, mp, mp, rows, 1.0, F, ldf, F, ldf, beta, G1, mp, sym, timed ? &t3[0] : nullptr));
-      NK_TRY(launch_gemm(ctx, true, false, mp, m, rows, 1.0, F, ldf, F + off_out, ldf, beta, G2t, m, GemmOpts(),
+      NK_TRY(launch_gemm(ctx, true, false, m, mp, rows, 1.0, F + off_out, ldf, F, ldf, beta, G2, mp, GemmOpts(),
                          timed ? &t3[1] : nullptr));
       NK_TRY(launch_gemm(ctx, true, false, m, m, rows, 1.0, F + off_out, ldf, F + off_out, ldf, beta, G3, m, sym,
                          timed ? &t3[2] : nullptr));
@@ -654,8 +655,8 @@ int nk_nystrom_fit(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int64
       int64_t oo = 0;
       bool first = true;
       for (const Piece& pc : ps) {
-        NK_TRY(launch_gemm(ctx, true, false, m, d, pc.len, 1.0, F + oo * ldf + off_out, ldf, y.ptr + pc.b * y.ld, y.ld,
-                           (first && ip == 0) ? 0.0 : 1.0, G4t, ldd));
+        NK_TRY(launch_gemm(ctx, true, false, d, m, pc.len, 1.0, y.ptr + pc.b * y.ld, y.ld, F + oo * ldf + off_out, ldf,
+                           (first && ip == 0) ? 0.0 : 1.0, G4, m));
         oo += pc.len;
         first = false;
       }
@@ -667,29 +668,29 @@ int nk_nystrom_fit(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int64
 
   // ---- the two regularised systems (regressors.py:151,162) are assembled, factorised AND solved on the main stream
   //      without waiting for the square root: with inner and inner_rec symmetric,
-  //        [A B] = S^-1 (inner^-1 cross^T)^T blkdiag(K_xo S^-1, I)        cross^T = G2t  (regressors.py:152-156)
-  //        C^T   = S^T (inner_rec^-1 left_rec^T)                           left_rec^T = G4t (regressors.py:163-166)
-  //      so the right-hand sides are G2t (m columns) and G4t (only d columns instead of the reference's m).
+  //        [A B] = S^-1 (cross inner^-1) blkdiag(K_xo S^-1, I)            cross = G2     (regressors.py:152-156)
+  //        C     = (left_rec inner_rec^-1) S                               left_rec = G4  (regressors.py:163-166)
+  //      so the right-hand sides are cross^T (m columns) and left_rec^T (only d columns instead of the reference's m).
   NK_TRY(launch_axpby2d(ctx, gamma_n, Kj_in, m, 1.0, G1, mp, m, m));               // inner = G1 + gamma_n*blkdiag(K, I)
   if (p > 0) NK_TRY(launch_add_diag(ctx, G1 + (int64_t)m * mp + m, mp, p, gamma_n));
   NK_TRY(launch_axpby2d(ctx, gamma_n, Kj, m, 1.0, G3, m, m, m));                   // inner_rec = gamma_n K + G3
-  double *Linv = nullptr, *Linv2 = nullptr, *Sinvt = nullptr, *T1t = nullptr, *X1 = nullptr, *V2t = nullptr, *Ct = nullptr;
+  double *Linv = nullptr, *Linv2 = nullptr, *Sinvt = nullptr, *V1 = nullptr, *T1t = nullptr, *X1 = nullptr, *Wc = nullptr,
+         *Ct = nullptr;
   const int nblk = (mp + CHOL_NB - 1) / CHOL_NB;
-  const int64_t ldv2 = p + (p & 1) + 2;
   NK_TRY(arena_alloc_t(ctx, (size_t)nblk * CHOL_NB * CHOL_NB, &Linv));
   NK_TRY(arena_alloc_t(ctx, (size_t)nblk * CHOL_NB * CHOL_NB, &Linv2));
   NK_TRY(arena_alloc_t(ctx, (size_t)m * m, &Sinvt));
+  NK_TRY(arena_alloc_t(ctx, (size_t)m * m, &V1));
   NK_TRY(arena_alloc_t(ctx, (size_t)m * m, &T1t));
   NK_TRY(arena_alloc_t(ctx, (size_t)m * m, &X1));
-  NK_TRY(arena_alloc_t(ctx, (size_t)m * ldv2, &V2t));
+  NK_TRY(arena_alloc_t(ctx, (size_t)m * ldd, &Wc));
   NK_TRY(arena_alloc_t(ctx, (size_t)m * ldd, &Ct));
   CholSys sys[2];
-  sys[0].P = G1; sys[0].ldp = mp; sys[0].m = mp; sys[0].Linv = Linv; sys[0].R = G2t; sys[0].ldr = m; sys[0].nrhs = m;
-  sys[1].P = G3; sys[1].ldp = m; sys[1].m = m; sys[1].Linv = Linv2; sys[1].R = G4t; sys[1].ldr = ldd; sys[1].nrhs = d;
+  sys[0].P = G1; sys[0].ldp = mp; sys[0].m = mp; sys[0].Linv = Linv; sys[0].extra = m;   // [inner; cross]
+  sys[1].P = G3; sys[1].ldp = m; sys[1].m = m; sys[1].Linv = Linv2; sys[1].extra = d;    // [inner_rec; left_rec]
   // both systems advance in lock step (paired launches); the per-block kernels are latency bound and leave the chip
   // mostly idle ...
-  NK_TRY(cholesky_lower_pair_async(ctx, sys, 2));
-  NK_TRY(cholesky_solve_pair(ctx, sys, 2));  // G2t <- V = inner^-1 cross^T ; G4t <- Wc = inner_rec^-1 left_rec^T
+  NK_TRY(cholesky_aug_pair_async(ctx, sys, 2));  // G2 <- cross inner^-1 (m x mp) ; G4 <- left_rec inner_rec^-1 (d x m)
   tr.mark("cholesky + solves issued");
 
   // ---- ... while S = K_mm^{1/2}, S^{-1} (regressors.py:140,163) runs on the side stream (GEMM bound) --------------------
@@ -709,17 +710,16 @@ int nk_nystrom_fit(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int64
   NK_TRY(cholesky_check_pair(ctx, sys, 2));
 
   // ---- operator products; every product is P^T Q with P stored contraction-major (fast TN engine) -----------------------
-  const double* V1 = G2t;                       // m x m   (rows 0..m-1 of V)
-  const double* V2 = G2t + (int64_t)m * m;      // p x m
+  //   [A B] = S^-1 (cross inner^-1) blkdiag(K_xo S^-1, I)   with  cross inner^-1 = [V1^T | V2^T] in G2
   NK_TRY(launch_transpose(ctx, mdl->Sinv, m, Sinvt, m, m, m));
+  NK_TRY(launch_transpose(ctx, G2, mp, V1, m, m, m));                                         // V1 (m x m)
   NK_TRY(launch_gemm(ctx, true, false, m, m, m, 1.0, Kxo, m, V1, m, 0.0, T1t, m));            // T1^T = K_xo^T V1
   NK_TRY(launch_gemm(ctx, true, false, m, m, m, 1.0, T1t, m, mdl->Sinv, m, 0.0, X1, m));      // X1 = V1^T K_xo S^-1
   NK_TRY(launch_gemm(ctx, true, false, m, m, m, 1.0, Sinvt, m, X1, m, 0.0, mdl->A, mp));      // A = S^-1 X1
-  if (p > 0) {
-    NK_TRY(launch_transpose(ctx, V2, m, V2t, ldv2, p, m));                                     // V2^T (m x p)
-    NK_TRY(launch_gemm(ctx, true, false, m, p, m, 1.0, Sinvt, m, V2t, ldv2, 0.0, mdl->B, mp)); // B = S^-1 V2^T
-  }
-  NK_TRY(launch_gemm(ctx, true, false, m, d, m, 1.0, mdl->S, m, G4t, ldd, 0.0, Ct, ldd));      // C^T = S^T Wc
+  if (p > 0) NK_TRY(launch_gemm(ctx, true, false, m, p, m, 1.0, Sinvt, m, G2 + m, mp, 0.0, mdl->B, mp));  // B = S^-1 V2^T
+  //   C = (left_rec inner_rec^-1) S : C^T = S^T Wc with Wc = G4^T
+  NK_TRY(launch_transpose(ctx, G4, m, Wc, ldd, d, m));
+  NK_TRY(launch_gemm(ctx, true, false, m, d, m, 1.0, mdl->S, m, Wc, ldd, 0.0, Ct, ldd));      // C^T = S^T Wc
   NK_TRY(launch_transpose(ctx, Ct, ldd, mdl->C, m, m, d));
   NK_TRY(launch_gemm(ctx, true, false, d, mp, m, 1.0, Ct, ldd, mdl->A, mp, 0.0, mdl->W, mp));  // W = C G (:167)
   NK_HIP(hipEventRecord(ev[5], ctx->stream));

@@ -167,6 +167,10 @@ struct CholSys {
   double* P = nullptr;   // matrix, overwritten by its lower factor
   int64_t ldp = 0;
   int m = 0;
+  // Augmented form (cholesky_aug_pair): `extra` further rows below the m x m matrix hold the right-hand sides
+  // TRANSPOSED (extra x m); the factorisation's panel / trailing updates carry them along (= forward substitution for
+  // free) and a backward pass leaves X^T = (P^-1 R)^T = R^T P^-1 in their place.
+  int extra = 0;
   double* Linv = nullptr;
   double* R = nullptr;   // right-hand sides (solve only), overwritten by the solution
   int64_t ldr = 0;
@@ -176,6 +180,7 @@ int cholesky_lower_pair(nk_ctx* ctx, const CholSys* sys, int nsys);
 int cholesky_lower_pair_async(nk_ctx* ctx, const CholSys* sys, int nsys);  // no host synchronisation
 int cholesky_check_pair(nk_ctx* ctx, const CholSys* sys, int nsys);       // verdict of the async factorisation
 int cholesky_solve_pair(nk_ctx* ctx, const CholSys* sys, int nsys);
+int cholesky_aug_pair_async(nk_ctx* ctx, const CholSys* sys, int nsys);  // factor + both substitutions, no host sync
 constexpr int CHOL_NB = 64;
 
 // matrix-vector step of the lifted recursion for up to 8 trajectories (nk_rollout.hip)

@@ -62,10 +62,12 @@ __device__ __forceinline__ void tile_from_index(int t, int tiles_m, int tiles_n,
     }
     tm = row;
     tn = row + rem;
-  } else {  // TRI_LOWER
+  } else {  // TRI_LOWER: tile row r holds min(r + 1, tiles_n) tiles (rows past the square part are full)
     int row = 0, rem = t;
-    while (rem >= row + 1) {
-      rem -= row + 1;
+    for (;;) {
+      const int cnt = row + 1 < tiles_n ? row + 1 : tiles_n;
+      if (rem < cnt) break;
+      rem -= cnt;
       ++row;
     }
     tm = row;
@@ -279,11 +281,14 @@ static int gemm_prepare(nk_ctx* ctx, bool transA, bool transB, int64_t M, int64_
   p.tiles_m = (int)((M + BM - 1) / BM);
   p.tiles_n = (int)((N + BN - 1) / BN);
   p.tri = opts.tri;
-  if (p.tri != TRI_FULL) NK_REQUIRE(M == N, "nk_gemm: triangular tile modes need a square C");
+  if (p.tri == TRI_UPPER_MIRROR) NK_REQUIRE(M == N, "nk_gemm: the mirrored mode needs a square C");
+  if (p.tri == TRI_LOWER) NK_REQUIRE(M >= N, "nk_gemm: the lower mode needs M >= N");
   p.alpha = alpha; p.beta = beta;
   p.vecA = aligned16(A) && (lda % 2 == 0);
   p.vecB = aligned16(B) && (ldb % 2 == 0);
-  const int ntiles = p.tri == TRI_FULL ? p.tiles_m * p.tiles_n : p.tiles_m * (p.tiles_m + 1) / 2;
+  int ntiles = p.tiles_m * p.tiles_n;
+  if (p.tri == TRI_UPPER_MIRROR) ntiles = p.tiles_m * (p.tiles_m + 1) / 2;
+  if (p.tri == TRI_LOWER) ntiles = p.tiles_n * (p.tiles_n + 1) / 2 + (p.tiles_m - p.tiles_n) * p.tiles_n;
   const int ktiles_total = (int)((K + BK - 1) / BK);
   int splitk = opts.splitk;
   if (splitk <= 0) {

@@ -453,6 +453,73 @@ int cholesky_lower_pair(nk_ctx* ctx, const CholSys* sys, int nsys) {
   return cholesky_check_pair(ctx, sys, nsys);
 }
 
+// Factorisation of [P; R^T] with the right-hand sides riding along as extra rows, then the backward substitution on
+// those rows.  Per block step: potrf (both systems), panel, trailing; then per block step of the backward pass two small
+// products.  The separate forward substitution (2 launches per block) disappears.
+int cholesky_aug_pair_async(nk_ctx* ctx, const CholSys* sys, int nsys) {
+  constexpr int NB = CHOL_NB;
+  NK_REQUIRE(nsys >= 1 && nsys <= 2, "cholesky_aug_pair: 1..2 systems");
+  NK_HIP(hipMemsetAsync(ctx->d_info, 0, 2 * sizeof(int), ctx->stream));
+  int nblk = 0;
+  for (int q = 0; q < nsys; ++q) nblk = std::max(nblk, (sys[q].m + NB - 1) / NB);
+  for (int jb = 0; jb < nblk; ++jb) {
+    const int j0 = jb * NB;
+    double* Ajj[2] = {nullptr, nullptr};
+    double* Li[2] = {nullptr, nullptr};
+    int64_t lda[2] = {0, 0};
+    int nbj[2] = {0, 0};
+    GemmCall panel[2], trail[2];
+    for (int q = 0; q < nsys; ++q) {
+      const CholSys& y = sys[q];
+      if (j0 >= y.m) continue;
+      nbj[q] = y.m - j0 < NB ? y.m - j0 : NB;
+      Ajj[q] = y.P + (int64_t)j0 * y.ldp + j0;
+      lda[q] = y.ldp;
+      Li[q] = y.Linv + (size_t)jb * NB * NB;
+      const int rem = y.m - j0 - nbj[q];      // rows of the square part below the diagonal block
+      const int rows = rem + y.extra;         // ... plus the right-hand-side rows
+      if (rows > 0) {
+        double* pnl = y.P + (int64_t)(j0 + nbj[q]) * y.ldp + j0;
+        panel[q].M = rows; panel[q].N = nbj[q]; panel[q].K = nbj[q];
+        panel[q].A = pnl; panel[q].lda = y.ldp; panel[q].B = Li[q]; panel[q].ldb = NB;
+        panel[q].C = pnl; panel[q].ldc = y.ldp;
+        if (rem > 0) {
+          trail[q].M = rows; trail[q].N = rem; trail[q].K = nbj[q]; trail[q].alpha = -1.0; trail[q].beta = 1.0;
+          trail[q].A = pnl; trail[q].lda = y.ldp; trail[q].B = pnl; trail[q].ldb = y.ldp;
+          trail[q].C = y.P + (int64_t)(j0 + nbj[q]) * y.ldp + (j0 + nbj[q]); trail[q].ldc = y.ldp;
+          trail[q].opts.tri = TRI_LOWER;  // lower tiles of the square part, full tiles for the extra rows
+        }
+      }
+    }
+    NK_TRY(launch_potrf_diag_pair(ctx, Ajj, lda, nbj, Li, nsys, jb));
+    NK_TRY(launch_gemm_pair(ctx, false, true, panel, nsys));
+    NK_TRY(launch_gemm_pair(ctx, false, true, trail, nsys));
+  }
+  // backward on the extra rows E (extra x m, now holding (L^-1 R)^T):  E <- E L^-1
+  for (int jb = nblk - 1; jb >= 0; --jb) {
+    const int j0 = jb * NB;
+    GemmCall diag[2], upd[2];
+    for (int q = 0; q < nsys; ++q) {
+      const CholSys& y = sys[q];
+      if (j0 >= y.m || y.extra <= 0) continue;
+      const int nbj = y.m - j0 < NB ? y.m - j0 : NB;
+      double* E = y.P + (int64_t)y.m * y.ldp;
+      const double* Li = y.Linv + (size_t)jb * NB * NB;
+      // E_j <- E_j Linv_jj   (in place: one n-tile, every workgroup reads exactly the rows it writes)
+      diag[q].M = y.extra; diag[q].N = nbj; diag[q].K = nbj; diag[q].A = E + j0; diag[q].lda = y.ldp; diag[q].B = Li;
+      diag[q].ldb = NB; diag[q].C = E + j0; diag[q].ldc = y.ldp;
+      if (j0 > 0) {  // E[:, 0:j0] -= E_j L[j-block, 0:j0]
+        upd[q].M = y.extra; upd[q].N = j0; upd[q].K = nbj; upd[q].alpha = -1.0; upd[q].beta = 1.0;
+        upd[q].A = E + j0; upd[q].lda = y.ldp; upd[q].B = y.P + (int64_t)j0 * y.ldp; upd[q].ldb = y.ldp;
+        upd[q].C = E; upd[q].ldc = y.ldp;
+      }
+    }
+    NK_TRY(launch_gemm_pair(ctx, false, false, diag, nsys));
+    NK_TRY(launch_gemm_pair(ctx, false, false, upd, nsys));
+  }
+  return NK_OK;
+}
+
 int cholesky_solve_pair(nk_ctx* ctx, const CholSys* sys, int nsys) {
   constexpr int NB = CHOL_NB;
   NK_REQUIRE(nsys >= 1 && nsys <= 2, "cholesky_solve_pair: 1..2 systems");
