@@ -702,6 +702,14 @@ int nk_nystrom_fit(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int64
     NK_HIP(hipEventRecord(ev[6], ctx->stream));
     NK_TRY(sqrtm_spd(ctx, Kj, m, m, mdl->S, mdl->Sinv, &it, &resid));
     NK_HIP(hipEventRecord(ev[7], ctx->stream));
+    // still on the side stream (the factorisation chain is usually not finished yet): S^-T and K_xo S^-1
+    NK_TRY(launch_transpose(ctx, mdl->Sinv, m, Sinvt, m, m, m));
+    if (same_centers) {
+      NK_TRY(launch_gemm(ctx, true, false, m, m, m, 1.0, Kxo, m, mdl->Sinv, m, 0.0, T1t, m));  // K(Z,Z) is bitwise symmetric
+    } else {
+      NK_TRY(launch_transpose(ctx, Kxo, m, X1, m, m, m));
+      NK_TRY(launch_gemm(ctx, true, false, m, m, m, 1.0, X1, m, mdl->Sinv, m, 0.0, T1t, m));
+    }
     NK_HIP(hipEventRecord(ctx->ev_join, ctx->stream));
   }
   NK_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
@@ -711,10 +719,9 @@ int nk_nystrom_fit(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int64
 
   // ---- operator products; every product is P^T Q with P stored contraction-major (fast TN engine) -----------------------
   //   [A B] = S^-1 (cross inner^-1) blkdiag(K_xo S^-1, I)   with  cross inner^-1 = [V1^T | V2^T] in G2
-  NK_TRY(launch_transpose(ctx, mdl->Sinv, m, Sinvt, m, m, m));
+  //   (T1t holds K_xo S^-1, computed on the side stream)
   NK_TRY(launch_transpose(ctx, G2, mp, V1, m, m, m));                                         // V1 (m x m)
-  NK_TRY(launch_gemm(ctx, true, false, m, m, m, 1.0, Kxo, m, V1, m, 0.0, T1t, m));            // T1^T = K_xo^T V1
-  NK_TRY(launch_gemm(ctx, true, false, m, m, m, 1.0, T1t, m, mdl->Sinv, m, 0.0, X1, m));      // X1 = V1^T K_xo S^-1
+  NK_TRY(launch_gemm(ctx, true, false, m, m, m, 1.0, V1, m, T1t, m, 0.0, X1, m));             // X1 = V1^T (K_xo S^-1)
   NK_TRY(launch_gemm(ctx, true, false, m, m, m, 1.0, Sinvt, m, X1, m, 0.0, mdl->A, mp));      // A = S^-1 X1
   if (p > 0) NK_TRY(launch_gemm(ctx, true, false, m, p, m, 1.0, Sinvt, m, G2 + m, mp, 0.0, mdl->B, mp));  // B = S^-1 V2^T
   //   C = (left_rec inner_rec^-1) S : C^T = S^T Wc with Wc = G4^T
