@@ -52,13 +52,14 @@ typedef struct nk_kernel_desc {
 
 /* per-fit diagnostics, all times in milliseconds measured with HIP events on the context's stream */
 typedef struct nk_fit_stats {
-  double ms_total;     /* whole nk_nystrom_fit call, device side */
-  double ms_upload;    /* host->HBM staging (0 when inputs are device pointers) */
-  double ms_kmat;      /* kernel-matrix builds K_nm (in, out) and K_mm */
-  double ms_gram;      /* the four Gram contractions */
-  double ms_sqrt;      /* matrix square root of K_mm */
-  double ms_solve;     /* Cholesky factorisations, triangular solves, operator products */
-  double ms_gram_kernel_avg; /* average duration of one launch of the dominant Gram kernel */
+  double ms_total;     /* whole nk_nystrom_fit call, device side (main stream, first to last event) */
+  double ms_upload;    /* host->HBM staging and K(Z,Z) (0 when inputs are device pointers) */
+  double ms_kmat;      /* the two n x m kernel blocks (of the first pass when the rows are processed in passes) */
+  double ms_gram;      /* the fused Gram launch (+ kernel blocks and Gram launches of later passes) */
+  double ms_sqrt;      /* matrix square root of K_mm on the side stream; OVERLAPS the factorisation chain */
+  double ms_solve;     /* operator products after the two streams join (the factorisations and substitutions run
+                          between ms_gram and this stage, concurrently with ms_sqrt) */
+  double ms_gram_kernel_avg; /* average duration of one fused Gram launch (HIP events around the kernel) */
   int32_t gram_kernel_launches;
   int32_t sqrt_iters;
   double sqrt_residual;      /* ||Z Y - I||_F / sqrt(m) at exit */

@@ -153,7 +153,6 @@ int launch_frob_minus_identity(nk_ctx* ctx, const double* M, int64_t ldm, int n,
 int launch_max_abs_rowsum(nk_ctx* ctx, const double* M, int64_t ldm, int n, double* d_out);
 int launch_colsum_sqdiff(nk_ctx* ctx, const double* P, int64_t ldp, const double* Y, int64_t ldy, int64_t rows,
                          int cols, double* d_colsum);  // colsum[j] = sum_i (P[i][j]-Y[i][j])^2
-int launch_recip(nk_ctx* ctx, const double* in, double* out, int n);
 
 // dense SPD machinery built on the GEMM engine
 int sqrtm_spd(nk_ctx* ctx, const double* P, int64_t ldp, int m, double* S, double* Sinv, int* iters, double* resid);

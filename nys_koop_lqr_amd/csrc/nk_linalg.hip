@@ -50,10 +50,6 @@ __global__ void fill_kernel(double* A, int64_t lda, int64_t rows, int64_t cols, 
     A[r * lda + c] = v;
   }
 }
-__global__ void recip_kernel(const double* in, double* out, int n) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) out[i] = 1.0 / in[i];
-}
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -203,11 +199,6 @@ int launch_fill(nk_ctx* ctx, double* A, int64_t lda, int64_t rows, int64_t cols,
   if (rows <= 0 || cols <= 0) return NK_OK;
   hipLaunchKernelGGL(fill_kernel, dim3(grid_for(rows * cols, ctx->num_cu)), dim3(256), 0, ctx->stream, A, lda, rows,
                      cols, v);
-  NK_HIP(hipGetLastError());
-  return NK_OK;
-}
-int launch_recip(nk_ctx* ctx, const double* in, double* out, int n) {
-  hipLaunchKernelGGL(recip_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, in, out, n);
   NK_HIP(hipGetLastError());
   return NK_OK;
 }
