@@ -314,7 +314,13 @@ int sqrtm_spd(nk_ctx* ctx, const double* P, int64_t ldp, int m, double* S, doubl
     // every product is issued as P^T Q with P stored contraction-major (fast LDS-DMA engine); Z and Y are only
     // symmetric up to rounding and must NOT be replaced by their transposes (that variant diverges), so true
     // transposes are kept alongside (written by the epilogue of the launch that produces Y and Z)
-    NK_TRY(launch_gemm(ctx, true, false, m, m, m, 1.0, Zt, m, Y, m, 0.0, M, m, sym));
+    if (it == 0) {
+      // Z_0 = I: M_0 = Y_0, taken as (Y_0 + Y_0^T)/2 so that T_0 is exactly symmetric (no GEMM)
+      NK_TRY(launch_copy2d(ctx, Y, m, M, m, m, m));
+      NK_TRY(launch_axpby2d(ctx, 0.5, Yt, m, 0.5, M, m, m, m));
+    } else {
+      NK_TRY(launch_gemm(ctx, true, false, m, m, m, 1.0, Zt, m, Y, m, 0.0, M, m, sym));
+    }
     // a_lo over-estimates the smallest eigenvalue of M: while it is below 1/2 the iteration cannot have converged
     // (||M - I||_F / sqrt(m) >= (1 - lambda_min) / sqrt(m)), so the residual reduction and its host round trip are
     // skipped during the growth phase
@@ -349,7 +355,17 @@ int sqrtm_spd(nk_ctx* ctx, const double* P, int64_t ldp, int m, double* S, doubl
       pr[0].Ct = Ytn; pr[0].ldct = m;
       pr[1].A = T; pr[1].B = Z; pr[1].C = Zn; pr[1].lda = pr[1].ldb = pr[1].ldc = m; pr[1].M = pr[1].N = m;
       pr[1].Ct = Ztn; pr[1].ldct = m;
-      if (tn_fast_ok(pr[0]) && tn_fast_ok(pr[1]) && m >= 128) {
+      if (it == 0) {
+        // Z_0 = I: Z_1 = T_0 (symmetric), only Y_0 T_0 needs a GEMM
+        if (tn_fast_ok(pr[0]) && m >= 128) {
+          NK_TRY(launch_gemm_tn_multi(ctx, pr, 1, m, 0));
+        } else {
+          NK_TRY(launch_gemm(ctx, true, false, m, m, m, 1.0, Yt, m, T, m, 0.0, Yn, m));
+          NK_TRY(launch_transpose(ctx, Yn, m, Ytn, m, m, m));
+        }
+        NK_TRY(launch_copy2d(ctx, T, m, Zn, m, m, m));
+        NK_TRY(launch_copy2d(ctx, T, m, Ztn, m, m, m));
+      } else if (tn_fast_ok(pr[0]) && tn_fast_ok(pr[1]) && m >= 128) {
         NK_TRY(launch_gemm_tn_multi(ctx, pr, 2, m, 0));
       } else {
         NK_TRY(launch_gemm(ctx, true, false, m, m, m, 1.0, Yt, m, T, m, 0.0, Yn, m));
