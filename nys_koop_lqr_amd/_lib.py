@@ -1,6 +1,7 @@
 """ctypes binding of libnyskoop.so (include/nyskoop.h).  Fails loudly: no library or no GPU => exception."""
 import ctypes as C
 import os
+import sys
 import threading
 
 import numpy as np
@@ -89,6 +90,14 @@ def load_library():
             if not os.path.exists(path):
                 raise NyskoopError(-6, f"{path} not found: build it with `python -c 'import __graft_entry__ as g; "
                                        f"g.build()'` or `make -C nys_koop_lqr_amd/csrc` (there is no CPU fallback)")
+            # torch wheels bundle their own HIP runtime (same SONAME as /opt/rocm's): if this library pulled in the system
+            # runtime first, a later `import torch` in the same process would find no GPUs.  When torch is installed,
+            # let it load its runtime first (plumbing only: nothing here calls into torch).
+            if os.environ.get("NYSKOOP_PRELOAD_TORCH", "1") == "1" and "torch" not in sys.modules:
+                try:
+                    import torch  # noqa: F401
+                except Exception:
+                    pass
             lib = C.CDLL(path)
             for name, (res, args) in SIGNATURES.items():
                 fn = getattr(lib, name)

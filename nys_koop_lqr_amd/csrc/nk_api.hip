@@ -565,7 +565,8 @@ int nk_nystrom_fit(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int64
     NK_TRY(arena_alloc_t(ctx, (size_t)maxlen, &sqr));
     NK_TRY(arena_alloc_t(ctx, (size_t)d * ldzt, &Zto));
     NK_TRY(arena_alloc_t(ctx, (size_t)m, &sqzo));
-    NK_TRY(launch_colmean(ctx, zo.ptr, zo.ld, m, d, center));
+    if (kd->type == NK_KERNEL_LINEAR) NK_TRY(launch_fill(ctx, center, d, 1, d, 0.0));  // x.y is not shift invariant
+    else NK_TRY(launch_colmean(ctx, zo.ptr, zo.ld, m, d, center));
     NK_TRY(prep_rows(ctx, zo.ptr, zo.ld, m, d, mdl->winv, center, Zto, ldzt, sqzo));
     if (same_centers) {
       Zti = Zto; sqzi = sqzo;

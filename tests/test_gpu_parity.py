@@ -288,6 +288,79 @@ def test_multi_pass_accumulation_matches_single_pass(nk, monkeypatch):
     assert relf(many_r.A, one_r.A) < 1e-9 and relf(many_r.weights, one_r.weights) < 1e-9
 
 
+def _synth(n, d, p, seed):
+    rng = np.random.default_rng(seed)
+    S = rng.standard_normal((n, d))
+    U = rng.standard_normal((n, p))
+    Y = np.tanh(S @ (rng.standard_normal((d, d)) * 0.9 / np.sqrt(d))) + U @ (rng.standard_normal((p, d)) * 0.1)
+    return np.hstack([S, U]), Y, rng
+
+
+@pytest.mark.parametrize("case", ["matern_gram_form", "distinct_in_out_landmarks", "no_inputs", "odd_sizes", "linear"])
+def test_fit_variants_vs_oracle(nk, O, case):
+    """Shapes and options the golden fixtures do not reach, against the oracle on the same seeded inputs: the Matern
+    epilogue of the Gram-form (MFMA) kernel blocks (d >= 32), separate input / output landmarks (regressors.py:133-134
+    only aliases them by default), n_inputs = 0, odd m / d / p (unaligned operands -> generic engine), linear kernel."""
+    if case == "matern_gram_form":
+        n, d, p, m, gamma = 900, 40, 2, 48, 1e-3
+        nkk, okk = nk.KernelWrapper(np.full(d, 6.0)), O.KernelWrapper(np.full(d, 6.0))
+    elif case == "distinct_in_out_landmarks":
+        n, d, p, m, gamma = 700, 33, 3, 40, 1e-3
+        nkk, okk = nk.ThreeDimensionalKernel(5.0, 6.0, 7.0, d), O.ThreeDimensionalKernel(5.0, 6.0, 7.0, d)
+    elif case == "no_inputs":
+        n, d, p, m, gamma = 500, 12, 0, 30, 1e-3
+        nkk, okk = nk.ThreeDimensionalKernel(3.0, 3.0, 3.0, d), O.ThreeDimensionalKernel(3.0, 3.0, 3.0, d)
+    elif case == "odd_sizes":
+        n, d, p, m, gamma = 333, 7, 1, 33, 1e-3
+        nkk, okk = nk.KernelWrapper(np.full(d, 2.5)), O.KernelWrapper(np.full(d, 2.5))
+    else:
+        n, d, p, m, gamma = 400, 50, 2, 20, 1e-2
+        nkk, okk = nk.LinearKernelWrapper(0.5), O.LinearKernelWrapper(0.5)
+    X, Y, rng = _synth(n, d, p, 11)
+    idx = rng.choice(n, m, replace=False)
+    reg = nk.KoopmanNystromRegressor(p, kernel=nkk, gamma=gamma, m=m)
+    ref = O.KoopmanNystromOracle(p, kernel=okk, gamma=gamma, m=m, faithful=(case != "linear"))
+    reg.nystrom_centers_output = Y.T[:, idx]
+    ref.nystrom_centers_output = Y.T[:, idx]
+    if case == "distinct_in_out_landmarks":
+        idx2 = rng.choice(n, m, replace=False)
+        reg.nystrom_centers_input = X[:, :d].T[:, idx2]
+        ref.nystrom_centers_input = X[:, :d].T[:, idx2]
+    reg.fit(X, Y)
+    ref.fit(X, Y)
+    tol = 1e-6 if case != "linear" else 1e-4  # the linear kernel's K_mm has rank d < m: jitter-dominated
+    errs = {k: relf(a, b) for k, a, b in (("A", reg.A, ref.A), ("C", reg.C, ref.C), ("W", reg.weights, ref.weights))}
+    if p:
+        errs["B"] = relf(reg.B, ref.B)
+    assert max(errs.values()) < tol, (case, errs)
+    assert relf(reg.predict(X[:40]), ref.predict(X[:40])) < tol
+    assert relf(reg.lift(X[:5, :d].T), ref.lift(X[:5, :d].T)) < tol
+
+
+def test_device_resident_inputs(nk, O):
+    """fit / predict / score on float64 device tensors (HBM-resident, as bench.py passes them) == host arrays."""
+    torch = pytest.importorskip("torch")
+    X, Y, rng = _synth(800, 36, 2, 3)
+    idx = rng.choice(800, 32, replace=False)
+    dev = torch.device("cuda", 0)
+    Xd, Yd = torch.from_numpy(X).to(dev), torch.from_numpy(Y).to(dev)
+    regs = []
+    for a, b in ((X, Y), (Xd, Yd)):
+        r = nk.KoopmanNystromRegressor(2, kernel=nk.ThreeDimensionalKernel(5.0, 5.0, 5.0, 36), gamma=1e-4, m=32)
+        r.nystrom_centers_output = Y.T[:, idx]
+        r.fit(a, b)
+        regs.append(r)
+    assert np.array_equal(regs[0].A, regs[1].A) and np.array_equal(regs[0].weights, regs[1].weights)
+    assert np.array_equal(regs[0].predict(X[:64]), regs[1].predict(Xd[:64]))
+    assert regs[0].score_neg_rmse(X[:100], Y[:100]) == regs[1].score_neg_rmse(Xd[:100], Yd[:100])
+    np.random.seed(4)
+    r = nk.KoopmanNystromRegressor(2, kernel=nk.ThreeDimensionalKernel(5.0, 5.0, 5.0, 36), gamma=1e-4, m=32)
+    r.fit(Xd, Yd)  # landmarks drawn from the global RNG and gathered from the device tensor
+    np.random.seed(4)
+    i2 = np.random.choice(np.arange(0, 800), size=32, replace=False)
+    assert np.array_equal(r.nystrom_centers_output, Y.T[:, i2])
+
+
 def test_gridsearch_scores_vs_sklearn_driving_reference(nk, golden):
     from nys_koop_lqr_amd import harness
     g = golden("f5_cloth_gridsearch.npz")
