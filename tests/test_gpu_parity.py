@@ -337,6 +337,29 @@ def test_fit_variants_vs_oracle(nk, O, case):
     assert relf(reg.lift(X[:5, :d].T), ref.lift(X[:5, :d].T)) < tol
 
 
+def test_large_query_counts_and_wide_batches(nk, O):
+    """lift / predict process queries in 32768-row chunks; rollouts switch from the matrix-vector kernel (<= 16
+    trajectories) to the GEMM engine: both sides of each switch agree with the oracle / with each other."""
+    X, Y, rng = _synth(50000, 4, 1, 21)
+    idx = rng.choice(2000, 16, replace=False)
+    reg = nk.KoopmanNystromRegressor(1, kernel=nk.KernelWrapper([1.5] * 4), gamma=1e-3, m=16)
+    ref = O.KoopmanNystromOracle(1, kernel=O.KernelWrapper([1.5] * 4), gamma=1e-3, m=16)
+    reg.nystrom_centers_output = Y.T[:, idx]
+    ref.nystrom_centers_output = Y.T[:, idx]
+    reg.fit(X[:2000], Y[:2000])
+    ref.fit(X[:2000], Y[:2000])
+    pred = reg.predict(X)  # 50000 queries: two chunks
+    q = np.r_[0:50, 32760:32780, 49950:50000]
+    assert pred.shape == (50000, 4) and relf(pred[q], ref.predict(X[q])) < 1e-7
+    assert relf(reg.lift(X[:40000, :4].T)[:, q[:70]], ref.lift(X[q[:70], :4].T)) < 1e-7
+    U = rng.standard_normal((24, 30, 1))
+    wide = reg.rollout(X[:24, :4], U)             # 24 trajectories: GEMM engine
+    narrow = np.stack([reg.rollout(X[b, :4], U[b].T).T for b in range(24)])  # one at a time: matrix-vector kernel
+    assert wide.shape == (24, 30, 4) and relf(wide, narrow) < 1e-10
+    sim_ref, _ = O.rollout(ref.A, ref.B, ref.C, ref.lift(X[3, :4].reshape(-1, 1)), U[3].T)
+    assert relf(wide[3].T, sim_ref) < 1e-7
+
+
 def test_device_resident_inputs(nk, O):
     """fit / predict / score on float64 device tensors (HBM-resident, as bench.py passes them) == host arrays."""
     torch = pytest.importorskip("torch")
