@@ -72,7 +72,7 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_f64_kernel(TnParams P) {
     if (q < P.nprob && gt >= P.p[q].tile_begin) pi = q;
   const TnDev pr = P.p[pi];
   int tm, tn;
-  if (EPI == 1) {
+  if (EPI >= 1) {
     // kernel-matrix launch: blocks b, b+8, ... share an XCD (round-robin dispatch), so give every XCD group its own
     // landmark tile columns tn = xcd + 8c for all sample tiles tm: the landmark panels (2 x 393 KB at m = 2000,
     // d = 384) stay resident in that XCD's L2 while the sample panels stream through once per group
@@ -193,39 +193,39 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_f64_kernel(TnParams P) {
           out[row * TBM + col] = acc[i][j][reg];
         }
   } else {
-    // kernel-matrix epilogue: squared distance from the Gram form, then the kernel function
+    // kernel-matrix epilogue (EPI = 1 RBF, 2 Matern-5/2, 3 linear; compile-time so that one formula is inlined):
+    // squared distance from the Gram form, then the kernel function
+    const bool interior = (tm + 1) * TBM <= pr.M && (tn + 1) * TBM <= pr.N;
     double sb[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int col = tn * TBM + wn * 64 + j * 16 + r16;
-      sb[j] = col < pr.N ? P.sqb[col] : 0.0;
+      sb[j] = (EPI != 3 && col < pr.N) ? P.sqb[col] : 0.0;
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
         const int row = tm * TBM + wm * 64 + i * 16 + g4 + 4 * reg;
-        if (row >= pr.M) continue;
-        const double sa = P.sqa[row];
-        double* orow = P.out + (int64_t)row * P.ldo;
+        if (!interior && row >= pr.M) continue;
+        const double sa = EPI != 3 ? P.sqa[row] : 0.0;
+        double* orow = P.out + (int64_t)row * P.ldo + tn * TBM + wn * 64 + r16;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const int col = tn * TBM + wn * 64 + j * 16 + r16;
-          if (col >= pr.N) continue;
           const double dot = acc[i][j][reg];
           double v;
-          if (P.ktype == NK_KERNEL_LINEAR) {
+          if (EPI == 3) {
             v = dot + P.sigma0sq;
           } else {
             const double D = fmax(sa + sb[j] - 2.0 * dot, 0.0);
-            if (P.ktype == NK_KERNEL_RBF) {
+            if (EPI == 1) {
               v = exp(-0.5 * D);
             } else {
               const double t = sqrt(D) * 2.23606797749978969641;
               v = (1.0 + t + t * t / 3.0) * exp(-t);
             }
           }
-          orow[col] = v;
+          if (interior || tn * TBM + wn * 64 + j * 16 + r16 < pr.N) orow[j * 16] = v;
         }
       }
   }
@@ -392,6 +392,10 @@ int launch_gemm_tn_multi(nk_ctx* ctx, const TnProblem* probs, int nprob, int64_t
                                hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES));
     NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_f64_kernel<1>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES));
+    NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_f64_kernel<2>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES));
+    NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_f64_kernel<3>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES));
     g_tn_attr_set = true;
   }
   if (ms_kernel) NK_HIP(hipEventRecord(ctx->ev[14], ctx->stream));
@@ -512,10 +516,19 @@ int launch_kmat_gram(nk_ctx* ctx, int ktype, const double* At, int64_t ldat, con
                                hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES));
     NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_f64_kernel<1>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES));
+    NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_f64_kernel<2>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES));
+    NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_f64_kernel<3>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES));
     g_tn_attr_set = true;
   }
   const unsigned grid = 8u * (unsigned)tmn * (unsigned)((tnn + 7) / 8);
-  hipLaunchKernelGGL(gemm_tn_f64_kernel<1>, dim3(grid), dim3(256), TN_LDS_BYTES, ctx->stream, P);
+  if (ktype == NK_KERNEL_RBF)
+    hipLaunchKernelGGL(gemm_tn_f64_kernel<1>, dim3(grid), dim3(256), TN_LDS_BYTES, ctx->stream, P);
+  else if (ktype == NK_KERNEL_MATERN52)
+    hipLaunchKernelGGL(gemm_tn_f64_kernel<2>, dim3(grid), dim3(256), TN_LDS_BYTES, ctx->stream, P);
+  else
+    hipLaunchKernelGGL(gemm_tn_f64_kernel<3>, dim3(grid), dim3(256), TN_LDS_BYTES, ctx->stream, P);
   NK_HIP(hipGetLastError());
   return NK_OK;
 }
