@@ -16,6 +16,8 @@ def init_process_group(backend=None):
     import torch.distributed as dist
     if dist.is_initialized():
         return dist.get_rank(), dist.get_world_size()
+    if "RANK" not in os.environ or "WORLD_SIZE" not in os.environ:
+        return 0, 1  # plain `python script.py`: single process, no process group needed
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
