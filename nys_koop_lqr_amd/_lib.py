@@ -218,8 +218,10 @@ def default_device():
 
 
 def get_context(device=None):
+    """The calling thread's context on `device` (a context is not thread-safe: one per thread and device; independent
+    fits issued from several threads overlap on the GPU)."""
     device = default_device() if device is None else int(device)
-    key = (os.getpid(), device)
+    key = (os.getpid(), threading.get_ident(), device)
     ctx = _contexts.get(key)
     if ctx is None:
         ctx = _contexts[key] = Context(device)
