@@ -489,7 +489,18 @@ int nk_nystrom_fit(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int64
 
   nk_model* mdl = nullptr;
   NK_TRY(model_alloc(ctx, m, d, p, &mdl));
-  struct Guard { nk_model* m; ~Guard() { if (m) nk_model_destroy(m); } } guard{mdl};
+  // on an early (error) return: drain both streams before the model buffers go back to the pool
+  struct Guard {
+    nk_ctx* c;
+    nk_model* m;
+    ~Guard() {
+      if (m) {
+        (void)hipStreamSynchronize(c->stream_main);
+        (void)hipStreamSynchronize(c->stream_side);
+        nk_model_destroy(m);
+      }
+    }
+  } guard{ctx, mdl};
   mdl->ktype = kd->type; mdl->sigma0 = kd->sigma0; mdl->jitter = jitter;
 
   tr.mark("validate + model_alloc");
