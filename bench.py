@@ -207,7 +207,7 @@ def main():
             "stages_ms": {k: avg(k) for k in ("ms_total", "ms_kmat", "ms_gram", "ms_sqrt", "ms_solve", "host_ms_drop",
                                               "host_ms_call", "host_ms_fetch")},
             "sqrt_iters": int(stats[-1]["sqrt_iters"]),
-            "roofline": {"bound": "mfma", "kernel": "nk::gemm_tn_f64_kernel (fused Gram / cross-Gram launch over n)",
+            "roofline": {"bound": "mfma", "kernel": "nk::gram_fused_f64_kernel (fused Gram / cross-Gram launch over n; engine nk_gemm_tn.hip)",
                          "achieved": achieved, "peak": MFMA_F64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / MFMA_F64_PEAK_TFLOPS, "traffic": traffic,
                          "flops_per_launch": flops_per_launch, "avg_launch_ms": avg("ms_gram_kernel_avg"),

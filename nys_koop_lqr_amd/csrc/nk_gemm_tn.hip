@@ -62,7 +62,7 @@ __device__ __forceinline__ void dma_row(const double* gsrc, double* lds_row) {
 }
 
 template <int EPI>
-__global__ void __launch_bounds__(256, 2) gemm_tn_f64_kernel(TnParams P) {
+__device__ __forceinline__ void tn_body(const TnParams& P) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int split = blockIdx.x % P.splitk;
   const int gt = blockIdx.x / P.splitk;
@@ -231,6 +231,16 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_f64_kernel(TnParams P) {
   }
 }
 
+// Entry points.  The fused Gram launch of the fit (the dominant kernel of the whole path) gets its own symbol so that
+// `rocprofv3 --kernel-trace --stats` reports it apart from the O(m^3) products that share the engine.
+template <int EPI>
+__global__ void __launch_bounds__(256, 2) gemm_tn_f64_kernel(TnParams P) {
+  tn_body<EPI>(P);
+}
+__global__ void __launch_bounds__(256, 2) gram_fused_f64_kernel(TnParams P) {
+  tn_body<0>(P);
+}
+
 struct TnRed {
   double* C;
   double* Ct;
@@ -390,6 +400,8 @@ int launch_gemm_tn_multi(nk_ctx* ctx, const TnProblem* probs, int nprob, int64_t
   if (!g_tn_attr_set) {
     NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_f64_kernel<0>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES));
+    NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gram_fused_f64_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES));
     NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_f64_kernel<1>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES));
     NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_f64_kernel<2>),
@@ -400,7 +412,10 @@ int launch_gemm_tn_multi(nk_ctx* ctx, const TnProblem* probs, int nprob, int64_t
   }
   if (ms_kernel) NK_HIP(hipEventRecord(ctx->ev[14], ctx->stream));
   P.sqa = P.sqb = nullptr; P.out = nullptr; P.ldo = 0; P.ktype = 0; P.sigma0sq = 0.0;
-  hipLaunchKernelGGL(gemm_tn_f64_kernel<0>, dim3((unsigned)(ntiles * splitk)), dim3(256), TN_LDS_BYTES, ctx->stream, P);
+  if (nprob >= 3)  // the fit's fused Gram launch
+    hipLaunchKernelGGL(gram_fused_f64_kernel, dim3((unsigned)(ntiles * splitk)), dim3(256), TN_LDS_BYTES, ctx->stream, P);
+  else
+    hipLaunchKernelGGL(gemm_tn_f64_kernel<0>, dim3((unsigned)(ntiles * splitk)), dim3(256), TN_LDS_BYTES, ctx->stream, P);
   NK_HIP(hipGetLastError());
   if (ms_kernel) NK_HIP(hipEventRecord(ctx->ev[15], ctx->stream));
   if (splitk > 1) {
@@ -513,6 +528,8 @@ int launch_kmat_gram(nk_ctx* ctx, int ktype, const double* At, int64_t ldat, con
   P.sqa = sqa; P.sqb = sqb; P.out = out; P.ldo = ldo; P.ktype = ktype; P.sigma0sq = sigma0 * sigma0;
   if (!g_tn_attr_set) {
     NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_f64_kernel<0>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES));
+    NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gram_fused_f64_kernel),
                                hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES));
     NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_f64_kernel<1>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES));
