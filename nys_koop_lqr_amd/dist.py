@@ -55,7 +55,7 @@ def all_gather_scores(local_scores, n_units, rank, world):
     return out
 
 
-def sharded_grid_search(X, Y, n_inputs, candidates, n_splits=5, centers=None, unit_fn=None, seed=None):
+def sharded_grid_search(X, Y, n_inputs, candidates, n_splits=5, centers=None, unit_fn=None, seed=None, workers=1):
     """Distributed counterpart of harness.grid_search_cv.  Landmarks: `centers[(c, f)]` if given, otherwise drawn
     from a per-unit RandomState(seed + unit index) so that the result does not depend on the world size.
     Every rank returns the same dict (split_scores, mean_test_score, best_index, best_params)."""
@@ -67,8 +67,7 @@ def sharded_grid_search(X, Y, n_inputs, candidates, n_splits=5, centers=None, un
     folds = harness.kfold_slices(X.shape[0], n_splits)
     units = harness.cv_work_list(len(candidates), n_splits)
     mine = shard_units(len(units), rank, world)
-    local = []
-    for u in mine:
+    def run(u):
         c, f = units[u]
         if centers is not None:
             idx = centers[(c, f)]
@@ -76,7 +75,14 @@ def sharded_grid_search(X, Y, n_inputs, candidates, n_splits=5, centers=None, un
             n_train = X.shape[0] - (folds[f][1] - folds[f][0])
             rs = np.random.RandomState((0 if seed is None else int(seed)) + u)
             idx = rs.choice(np.arange(0, n_train), size=candidates[c]["m"], replace=False)
-        local.append(unit_fn(X, Y, n_inputs, candidates[c], folds[f], idx))
+        return unit_fn(X, Y, n_inputs, candidates[c], folds[f], idx)
+
+    if workers > 1 and len(mine) > 1:  # several latency-bound fits in flight per GPU (one context per thread)
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=workers) as pool:
+            local = list(pool.map(run, mine))
+    else:
+        local = [run(u) for u in mine]
     if world > 1:
         flat = all_gather_scores(np.asarray(local, dtype=np.float64), len(units), rank, world)
     else:

@@ -59,13 +59,16 @@ def cv_unit_score(X, Y, n_inputs, params, fold, centers_idx=None):
     return reg.score_neg_rmse(X[lo:hi], Y[lo:hi])
 
 
-def grid_search_cv(X, Y, n_inputs, candidates, n_splits=5, centers=None, work=None):
+def grid_search_cv(X, Y, n_inputs, candidates, n_splits=5, centers=None, work=None, workers=1):
     """learn_hyperparams (benchmark_lqr_cloth.py:39-66 and the classic/hjb twins) without sklearn's process pool.
 
     candidates: list of dicts with keys kernel / gamma / m.  centers: optional {(c, f): landmark indices into the
     training rows}; otherwise indices are drawn from the global NumPy RNG in GridSearchCV's order, which reproduces
     sklearn with n_jobs=1 exactly.  work: optional subset of (candidate, fold) units (for sharding over GPUs); units
-    not evaluated are NaN.  Returns split_scores (n_cand x n_splits), mean_test_score, best_index.
+    not evaluated are NaN.  workers: host threads issuing units concurrently on this GPU (each thread has its own
+    context and streams; small fits are latency bound, so several in flight fill the chip).  The landmark draws happen
+    up front in GridSearchCV's order, so the scores do not depend on `workers`.
+    Returns split_scores (n_cand x n_splits), mean_test_score, best_index.
     """
     X = np.ascontiguousarray(X, dtype=np.float64)
     Y = np.ascontiguousarray(Y, dtype=np.float64)
@@ -73,14 +76,28 @@ def grid_search_cv(X, Y, n_inputs, candidates, n_splits=5, centers=None, work=No
     scores = np.full((len(candidates), n_splits), np.nan)
     units = cv_work_list(len(candidates), n_splits)
     mine = set(units if work is None else work)
+    todo = []
     for (c, f) in units:
-        idx = None if centers is None else centers[(c, f)]
-        if (c, f) not in mine:
-            if centers is None:  # keep the RNG stream aligned with the serial sweep
-                n_train = X.shape[0] - (folds[f][1] - folds[f][0])
-                np.random.choice(np.arange(0, n_train), size=candidates[c]["m"], replace=False)
-            continue
-        scores[c, f] = cv_unit_score(X, Y, n_inputs, candidates[c], folds[f], idx)
+        if centers is not None:
+            idx = centers[(c, f)]
+        else:  # drawn for every unit, evaluated or not: keeps the RNG stream aligned with the serial sweep
+            n_train = X.shape[0] - (folds[f][1] - folds[f][0])
+            idx = np.random.choice(np.arange(0, n_train), size=candidates[c]["m"], replace=False)
+        if (c, f) in mine:
+            todo.append((c, f, idx))
+
+    def run(item):
+        c, f, idx = item
+        return c, f, cv_unit_score(X, Y, n_inputs, candidates[c], folds[f], idx)
+
+    if workers > 1 and len(todo) > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=workers) as pool:
+            results = list(pool.map(run, todo))
+    else:
+        results = [run(item) for item in todo]
+    for c, f, sc in results:
+        scores[c, f] = sc
     mean = scores.mean(axis=1)
     best = int(np.nanargmax(mean)) if np.all(np.isfinite(mean)) else -1
     return dict(split_scores=scores, mean_test_score=mean, best_index=best,

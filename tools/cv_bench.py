@@ -16,8 +16,15 @@ X, Y = synth(1010, 192, 6)
 cands = [dict(kernel=nk.ThreeDimensionalKernel(l, l, l, 192), gamma=g, m=500) for l in (10., 20., 40.) for g in (1e-5, 1e-4, 1e-3)]
 np.random.seed(0)
 harness.grid_search_cv(X, Y, 6, cands[:1], n_splits=5)  # warm-up
-t0 = time.perf_counter(); res = harness.grid_search_cv(X, Y, 6, cands, n_splits=5); t1 = time.perf_counter()
-print(f"CV sweep n=1010 m=500 d=192: {len(cands) * 5} units in {t1 - t0:.3f} s = {len(cands) * 5 / (t1 - t0):.1f} units/s ({(t1 - t0) / (len(cands) * 5) * 1e3:.2f} ms per fit+score)")
+base = None
+for workers in (1, 2, 4, 8):
+    np.random.seed(0)
+    harness.grid_search_cv(X, Y, 6, cands[:2], n_splits=5, workers=workers)  # per-thread warm-up
+    np.random.seed(0)
+    t0 = time.perf_counter(); res = harness.grid_search_cv(X, Y, 6, cands, n_splits=5, workers=workers); t1 = time.perf_counter()
+    if base is None: base = res["split_scores"]
+    assert np.array_equal(base, res["split_scores"]), "scores must not depend on the number of workers"
+    print(f"CV sweep n=1010 m=500 d=192, workers={workers}: {len(cands) * 5} units in {t1 - t0:.3f} s = {len(cands) * 5 / (t1 - t0):.1f} units/s ({(t1 - t0) / (len(cands) * 5) * 1e3:.2f} ms per fit+score)")
 # --- per-call latencies
 for (n, d, p, m) in ((3030, 192, 6, 100), (20000, 384, 6, 2000)):
     X, Y = synth(n, d, p)
