@@ -210,7 +210,7 @@ def pinned_empty(shape):
     return np.frombuffer(buf, dtype=np.float64).reshape(shape)
 
 
-_contexts = {}
+_tls = threading.local()
 
 
 def default_device():
@@ -219,10 +219,29 @@ def default_device():
 
 def get_context(device=None):
     """The calling thread's context on `device` (a context is not thread-safe: one per thread and device; independent
-    fits issued from several threads overlap on the GPU)."""
+    fits issued from several threads overlap on the GPU).  Contexts live in thread-local storage, so a worker thread's
+    streams and workspace are released when the thread ends."""
     device = default_device() if device is None else int(device)
-    key = (os.getpid(), threading.get_ident(), device)
-    ctx = _contexts.get(key)
+    ctxs = getattr(_tls, "ctxs", None)
+    if ctxs is None:
+        ctxs = _tls.ctxs = {}
+    key = (os.getpid(), device)
+    ctx = ctxs.get(key)
     if ctx is None:
-        ctx = _contexts[key] = Context(device)
+        ctx = ctxs[key] = Context(device)
     return ctx
+
+
+_pools = {}
+_pools_lock = threading.Lock()
+
+
+def worker_pool(workers):
+    """A persistent pool of `workers` host threads (their contexts, streams and workspaces are reused across calls)."""
+    from concurrent.futures import ThreadPoolExecutor
+    with _pools_lock:
+        key = (os.getpid(), int(workers))
+        pool = _pools.get(key)
+        if pool is None:
+            pool = _pools[key] = ThreadPoolExecutor(max_workers=int(workers), thread_name_prefix="nyskoop")
+        return pool

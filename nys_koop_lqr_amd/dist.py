@@ -78,9 +78,8 @@ def sharded_grid_search(X, Y, n_inputs, candidates, n_splits=5, centers=None, un
         return unit_fn(X, Y, n_inputs, candidates[c], folds[f], idx)
 
     if workers > 1 and len(mine) > 1:  # several latency-bound fits in flight per GPU (one context per thread)
-        from concurrent.futures import ThreadPoolExecutor
-        with ThreadPoolExecutor(max_workers=workers) as pool:
-            local = list(pool.map(run, mine))
+        from ._lib import worker_pool
+        local = list(worker_pool(workers).map(run, mine))
     else:
         local = [run(u) for u in mine]
     if world > 1:

@@ -7,6 +7,7 @@ import itertools
 
 import numpy as np
 
+from . import _lib
 from .regressors import KoopmanNystromRegressor
 
 
@@ -91,9 +92,7 @@ def grid_search_cv(X, Y, n_inputs, candidates, n_splits=5, centers=None, work=No
         return c, f, cv_unit_score(X, Y, n_inputs, candidates[c], folds[f], idx)
 
     if workers > 1 and len(todo) > 1:
-        from concurrent.futures import ThreadPoolExecutor
-        with ThreadPoolExecutor(max_workers=workers) as pool:
-            results = list(pool.map(run, todo))
+        results = list(_lib.worker_pool(workers).map(run, todo))
     else:
         results = [run(item) for item in todo]
     for c, f, sc in results:
