@@ -62,7 +62,8 @@ typedef struct nk_fit_stats {
   double ms_gram_kernel_avg; /* average duration of one fused Gram launch (HIP events around the kernel) */
   int32_t gram_kernel_launches;
   int32_t sqrt_iters;
-  double sqrt_residual;      /* ||Z Y - I||_F / sqrt(m) at exit */
+  double sqrt_residual;      /* ||X^T X - I||_F / sqrt(m) at the last convergence check (< 1e-7; the returned
+                                square root is one quadratically convergent step beyond that iterate) */
   double gram_flops;         /* algorithmic flop of the Gram contractions actually issued */
   double kmat_pairs;         /* number of (row,row,dim) triples evaluated by the kernel-matrix builds */
 } nk_fit_stats;

@@ -53,6 +53,7 @@ static int arena_reset_one(nk_ctx* ctx, Arena& a) {
   if (a.chunks.size() > 1) {  // coalesce: steady state is one chunk and no hipMalloc on the hot path
     NK_HIP(hipStreamSynchronize(ctx->stream_main));
     NK_HIP(hipStreamSynchronize(ctx->stream_side));
+    NK_HIP(hipStreamSynchronize(ctx->stream_prep));
     size_t total = 0;
     for (auto& c : a.chunks) {
       total += c.cap;
@@ -364,12 +365,18 @@ int nk_create(int device, nk_ctx** out) {
   nk_ctx* ctx = new nk_ctx();
   ctx->device = device;
   ctx->num_cu = prop.multiProcessorCount;
-  // main stream: highest priority (it carries the latency-bound factorisation chains, whose tiny kernels must not queue
-  // behind the GEMM workgroups of the side stream); side stream: lowest priority
+  // Three priority levels (the dispatcher serves hardware queues in strict priority order, so a queue with pending
+  // workgroups starves every lower one):
+  //   prep stream: highest -- a short latency-bound chain queued beside the big kernel-block / Gram launches of the main
+  //                stream; its tiny kernels must get the first CU slots that free up;
+  //   main stream: middle  -- the big launches and the factorisation chains;
+  //   side stream: lowest  -- the GEMM-bound square-root iteration that fills the chip beside the factorisation chain.
   int prio_lo = 0, prio_hi = 0;
   NK_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-  NK_HIP(hipStreamCreateWithPriority(&ctx->stream_main, hipStreamNonBlocking, prio_hi));
+  const int prio_mid = (prio_lo - prio_hi >= 2) ? (prio_lo + prio_hi) / 2 : prio_hi;
+  NK_HIP(hipStreamCreateWithPriority(&ctx->stream_main, hipStreamNonBlocking, prio_mid));
   NK_HIP(hipStreamCreateWithPriority(&ctx->stream_side, hipStreamNonBlocking, prio_lo));
+  NK_HIP(hipStreamCreateWithPriority(&ctx->stream_prep, hipStreamNonBlocking, prio_hi));
   ctx->stream = ctx->stream_main;
   ctx->cur_arena = &ctx->arena;
   NK_HIP(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
@@ -390,11 +397,13 @@ int nk_destroy(nk_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream_main);
   (void)hipStreamSynchronize(ctx->stream_side);
+  (void)hipStreamSynchronize(ctx->stream_prep);
   for (auto& c : ctx->arena.chunks) (void)hipFree(c.base);
   for (auto& c : ctx->arena_side.chunks) (void)hipFree(c.base);
   (void)hipEventDestroy(ctx->ev_fork);
   (void)hipEventDestroy(ctx->ev_join);
   (void)hipStreamDestroy(ctx->stream_side);
+  (void)hipStreamDestroy(ctx->stream_prep);
   (void)hipFree(ctx->d_info);
   (void)hipFree(ctx->d_scalars);
   if (ctx->d_zeros) (void)hipFree(ctx->d_zeros);
@@ -497,6 +506,7 @@ int nk_nystrom_fit(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int64
       if (m) {
         (void)hipStreamSynchronize(c->stream_main);
         (void)hipStreamSynchronize(c->stream_side);
+        (void)hipStreamSynchronize(c->stream_prep);
         nk_model_destroy(m);
       }
     }
@@ -523,6 +533,7 @@ int nk_nystrom_fit(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int64
   NK_TRY(launch_kmat(ctx, kd->type, zo.ptr, zo.ld, m, zo.ptr, zo.ld, m, d, mdl->winv, kd->sigma0, Kmm, m));
   NK_TRY(launch_copy2d(ctx, Kmm, m, Kj, m, m, m));
   NK_TRY(launch_add_diag(ctx, Kj, m, m, jitter));
+  NK_HIP(hipEventRecord(ev[8], ctx->stream));  // K_mm + jitter is ready (preparation stream: sqrtm_prepare)
   if (same_centers) {
     Kj_in = Kj;
     Kxo = Kmm;
@@ -675,8 +686,19 @@ int nk_nystrom_fit(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int64
     }
   }
   NK_HIP(hipEventRecord(ev[3], ctx->stream));
-  NK_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));  // the side stream (square root) starts when the Gram launch is done
+  NK_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));  // the square-root iteration starts when the Gram launch is done
   tr.mark("gram issued");
+
+  // ---- preparation stream (queued behind the kernel-block / Gram launches so that the main stream is never kept
+  //      waiting for the host): Cholesky factor of K_mm + jitter and its inverse, the latency-bound half of the matrix
+  //      square root.  Small kernels that slip into the gaps of the big launches.
+  SqrtPlan splan;
+  {
+    SideScope prep(ctx, ctx->stream_prep);
+    NK_HIP(hipStreamWaitEvent(ctx->stream, ev[8], 0));
+    NK_TRY(sqrtm_prepare(ctx, Kj, m, m, &splan));
+    NK_HIP(hipEventRecord(ev[9], ctx->stream));
+  }
 
   // ---- the two regularised systems (regressors.py:151,162) are assembled, factorised AND solved on the main stream
   //      without waiting for the square root: with inner and inner_rec symmetric,
@@ -711,8 +733,9 @@ int nk_nystrom_fit(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int64
   {
     SideScope side(ctx);
     NK_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_fork, 0));
+    NK_HIP(hipStreamWaitEvent(ctx->stream, ev[9], 0));
     NK_HIP(hipEventRecord(ev[6], ctx->stream));
-    NK_TRY(sqrtm_spd(ctx, Kj, m, m, mdl->S, mdl->Sinv, &it, &resid));
+    NK_TRY(sqrtm_finish(ctx, &splan, mdl->S, mdl->Sinv, &it, &resid));
     NK_HIP(hipEventRecord(ev[7], ctx->stream));
     // still on the side stream (the factorisation chain is usually not finished yet): S^-T and K_xo S^-1
     NK_TRY(launch_transpose(ctx, mdl->Sinv, m, Sinvt, m, m, m));

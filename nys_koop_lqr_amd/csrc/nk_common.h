@@ -58,7 +58,10 @@ struct nk_ctx {
   int device = 0;
   hipStream_t stream = nullptr;       // CURRENT stream: every launcher uses this (swapped by nk::SideScope)
   hipStream_t stream_main = nullptr;
-  hipStream_t stream_side = nullptr;  // second stream for work that is independent of the main chain
+  hipStream_t stream_side = nullptr;  // second stream (lowest priority) for GEMM-bound work beside the main chain
+  hipStream_t stream_prep = nullptr;  // third stream (highest priority) for small latency-bound work queued early: its
+                                      // kernels must get CU slots while a big main-stream launch still has workgroups
+                                      // pending (the dispatcher serves queues in strict priority order)
   nk::Arena arena;                    // workspace of the main stream
   nk::Arena arena_side;               // workspace of the side stream (slabs must not be shared across streams)
   nk::Arena* cur_arena = nullptr;
@@ -88,13 +91,14 @@ struct nk_model {
 
 namespace nk {
 
-// Route launches and workspace allocations to the side stream for the lifetime of the scope.
+// Route launches and workspace allocations to the side stream (or the given one; the side arena is shared, so work on the
+// two auxiliary streams must be ordered by events) for the lifetime of the scope.
 struct SideScope {
   nk_ctx* c;
   hipStream_t s0;
   Arena* a0;
-  explicit SideScope(nk_ctx* ctx) : c(ctx), s0(ctx->stream), a0(ctx->cur_arena) {
-    c->stream = c->stream_side;
+  explicit SideScope(nk_ctx* ctx, hipStream_t s = nullptr) : c(ctx), s0(ctx->stream), a0(ctx->cur_arena) {
+    c->stream = s ? s : c->stream_side;
     c->cur_arena = &c->arena_side;
   }
   ~SideScope() {
@@ -102,6 +106,10 @@ struct SideScope {
     c->cur_arena = a0;
   }
 };
+
+// factorisation failure flags: slots 0-1 belong to the main stream, 2-3 to the side stream (each stream may have a paired
+// factorisation in flight)
+inline int info_base(const nk_ctx* c) { return c->stream != c->stream_main ? 2 : 0; }
 
 // ---- workspace -------------------------------------------------------------------------------------------
 int arena_reset(nk_ctx* ctx);
@@ -156,6 +164,22 @@ int launch_colsum_sqdiff(nk_ctx* ctx, const double* P, int64_t ldp, const double
 
 // dense SPD machinery built on the GEMM engine
 int sqrtm_spd(nk_ctx* ctx, const double* P, int64_t ldp, int m, double* S, double* Sinv, int* iters, double* resid);
+// the same in two phases, so that a caller can queue the latency-bound half (Cholesky factor of P and its inverse) early
+// and the GEMM-bound half (Newton-Schulz polar iteration) later, both on the current stream; no host synchronisation in
+// sqrtm_prepare.  The plan's buffers live in the current arena until sqrtm_finish returns.
+struct SqrtPlan {
+  const double* P = nullptr;
+  int64_t ldp = 0;
+  int m = 0;
+  double* W = nullptr;     // 2m x m: lower Cholesky factor L of P on top, L^-T below
+  double* Linv = nullptr;  // inverted diagonal blocks
+  double* X0 = nullptr;    // L^T / sqrt(c)   (c = ||P||_inf)
+  double* X0t = nullptr;   // L / sqrt(c)
+  double* d_sc = nullptr;  // device scalars: c, ||P||_F^2, trace(P)
+  ArenaMark mark{0, 0};
+};
+int sqrtm_prepare(nk_ctx* ctx, const double* P, int64_t ldp, int m, SqrtPlan* plan);
+int sqrtm_finish(nk_ctx* ctx, SqrtPlan* plan, double* S, double* Sinv, int* iters, double* resid);
 // in-place lower Cholesky of P (m x m, ld), Linv workspace holds inverted diagonal blocks
 int cholesky_lower(nk_ctx* ctx, double* P, int64_t ldp, int m, double* Linv /* nblk*NB*NB */);
 int cholesky_solve(nk_ctx* ctx, const double* L, int64_t ldl, int m, const double* Linv, double* R, int64_t ldr,
@@ -170,6 +194,7 @@ struct CholSys {
   // TRANSPOSED (extra x m); the factorisation's panel / trailing updates carry them along (= forward substitution for
   // free) and a backward pass leaves X^T = (P^-1 R)^T = R^T P^-1 in their place.
   int extra = 0;
+  bool backward = true;  // false: stop after the factorisation (the extra rows then hold R^T L^-T)
   double* Linv = nullptr;
   double* R = nullptr;   // right-hand sides (solve only), overwritten by the solution
   int64_t ldr = 0;

@@ -254,9 +254,13 @@ struct TnRedParams {
   const double* slab;
 };
 
-// one workgroup per tile: C = alpha * sum_s slab[tile][s] + beta * C (bounds, mirror)
+// C = alpha * sum_s slab[tile][s] + beta * C (bounds, mirror, transposed copy).  RPARTS workgroups per tile, each summing
+// a 16-row band of the slices in slice order (deterministic) with 16-byte loads; the mirrored / transposed copies go
+// through LDS so that their stores are 64-byte runs instead of single strided doubles.
+constexpr int RPARTS = 8;
 __global__ void __launch_bounds__(256) gemm_tn_reduce_kernel(TnRedParams P) {
-  const int gt = blockIdx.x;
+  __shared__ double sh[16][130];
+  const int gt = blockIdx.x / RPARTS, part = blockIdx.x % RPARTS;
   int pi = 0;
 #pragma unroll
   for (int q = 1; q < TN_MAXP; ++q)
@@ -278,17 +282,47 @@ __global__ void __launch_bounds__(256) gemm_tn_reduce_kernel(TnRedParams P) {
       tn = row + rem;
     }
   }
-  const double* base = P.slab + (int64_t)gt * P.splitk * (TBM * TBM);
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  const double* base = P.slab + (int64_t)gt * P.splitk * (TBM * TBM) + part * (16 * TBM) + threadIdx.x * 2;
+  d2 s[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) s[i] = d2{0.0, 0.0};
+  for (int k = 0; k < P.splitk; ++k) {
+    const double* bk = base + (int64_t)k * (TBM * TBM);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s[i] += *reinterpret_cast<const d2*>(bk + 512 * i);
+  }
   const bool mirror = pr.tri == TRI_UPPER_MIRROR && tm != tn;
-  for (int e = threadIdx.x; e < TBM * TBM; e += 256) {
-    const int r = e >> 7, c = e & 127;
-    const int row = tm * TBM + r, col = tn * TBM + c;
-    if (row >= pr.M || col >= pr.N) continue;
-    double s = 0.0;
-    for (int k = 0; k < P.splitk; ++k) s += base[(int64_t)k * (TBM * TBM) + e];
-    double v = pr.alpha * s;
-    if (pr.beta != 0.0) v += pr.beta * pr.C[(int64_t)row * pr.ldc + col];
-    pr.C[(int64_t)row * pr.ldc + col] = v;
+  const bool transposed = mirror || pr.Ct != nullptr;
+  const int row0 = tm * TBM + part * 16, col0 = tn * TBM;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = threadIdx.x * 2 + 512 * i;
+    const int r = idx >> 7, c = idx & 127;
+    const int row = row0 + r;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int col = col0 + c + h;
+      double v = 0.0;
+      if (row < pr.M && col < pr.N) {
+        v = pr.alpha * s[i][h];
+        if (pr.beta != 0.0) v += pr.beta * pr.C[(int64_t)row * pr.ldc + col];
+        pr.C[(int64_t)row * pr.ldc + col] = v;
+      }
+      if (transposed) sh[r][c + h] = v;
+    }
+  }
+  if (!transposed) return;
+  __syncthreads();
+  // thread t: column c = t / 2, rows 8 * (t & 1) .. + 8 of this band
+  const int c = threadIdx.x >> 1, rb = (threadIdx.x & 1) * 8;
+  const int col = col0 + c;
+  if (col >= pr.N) return;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int row = row0 + rb + q;
+    if (row >= pr.M) break;
+    const double v = sh[rb + q][c];
     if (mirror) pr.C[(int64_t)col * pr.ldc + row] = v;
     if (pr.Ct) pr.Ct[(int64_t)col * pr.ldct + row] = v;
   }
@@ -419,7 +453,7 @@ int launch_gemm_tn_multi(nk_ctx* ctx, const TnProblem* probs, int nprob, int64_t
   NK_HIP(hipGetLastError());
   if (ms_kernel) NK_HIP(hipEventRecord(ctx->ev[15], ctx->stream));
   if (splitk > 1) {
-    hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((unsigned)ntiles), dim3(256), 0, ctx->stream, R);
+    hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((unsigned)ntiles * RPARTS), dim3(256), 0, ctx->stream, R);
     NK_HIP(hipGetLastError());
   }
   if (ms_kernel && sync_timing) {  // otherwise the caller reads ev[14] -> ev[15] after its own synchronisation

@@ -251,7 +251,8 @@ static int read_scalar(nk_ctx* ctx, const double* d_ptr, double* out) {
   return NK_OK;
 }
 
-int sqrtm_spd(nk_ctx* ctx, const double* P, int64_t ldp, int m, double* S, double* Sinv, int* iters, double* resid) {
+static int sqrtm_spd_coupled(nk_ctx* ctx, const double* P, int64_t ldp, int m, double* S, double* Sinv, int* iters,
+                             double* resid) {
   const ArenaMark mk = arena_mark(ctx);
   const size_t mm = (size_t)m * m;
   double *Y = nullptr, *Z = nullptr, *Yn = nullptr, *Zn = nullptr, *M = nullptr, *T = nullptr;
@@ -403,7 +404,7 @@ int launch_potrf_diag_pair(nk_ctx* ctx, double* const* Ajj, const int64_t* lda, 
 int cholesky_lower_pair_async(nk_ctx* ctx, const CholSys* sys, int nsys) {
   constexpr int NB = CHOL_NB;
   NK_REQUIRE(nsys >= 1 && nsys <= 2, "cholesky_lower_pair: 1..2 systems");
-  NK_HIP(hipMemsetAsync(ctx->d_info, 0, 2 * sizeof(int), ctx->stream));
+  NK_HIP(hipMemsetAsync(ctx->d_info + info_base(ctx), 0, 2 * sizeof(int), ctx->stream));
   int nblk = 0;
   for (int q = 0; q < nsys; ++q) nblk = std::max(nblk, (sys[q].m + NB - 1) / NB);
   for (int jb = 0; jb < nblk; ++jb) {
@@ -443,9 +444,10 @@ int cholesky_lower_pair_async(nk_ctx* ctx, const CholSys* sys, int nsys) {
 
 // Host-side verdict of the factorisations queued by cholesky_lower_pair_async (synchronises the current stream).
 int cholesky_check_pair(nk_ctx* ctx, const CholSys* sys, int nsys) {
-  NK_HIP(hipMemcpyAsync(ctx->h_info, ctx->d_info, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  const int ib = info_base(ctx);
+  NK_HIP(hipMemcpyAsync(ctx->h_info + ib, ctx->d_info + ib, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   NK_HIP(hipStreamSynchronize(ctx->stream));
-  const int* info = ctx->h_info;
+  const int* info = ctx->h_info + ib;
   for (int q = 0; q < nsys; ++q)
     if (info[q] != 0) {
       set_error("Cholesky: non-positive pivot at index %d of %d (system %d is numerically rank deficient; the "
@@ -466,7 +468,7 @@ int cholesky_lower_pair(nk_ctx* ctx, const CholSys* sys, int nsys) {
 int cholesky_aug_pair_async(nk_ctx* ctx, const CholSys* sys, int nsys) {
   constexpr int NB = CHOL_NB;
   NK_REQUIRE(nsys >= 1 && nsys <= 2, "cholesky_aug_pair: 1..2 systems");
-  NK_HIP(hipMemsetAsync(ctx->d_info, 0, 2 * sizeof(int), ctx->stream));
+  NK_HIP(hipMemsetAsync(ctx->d_info + info_base(ctx), 0, 2 * sizeof(int), ctx->stream));
   int nblk = 0;
   for (int q = 0; q < nsys; ++q) nblk = std::max(nblk, (sys[q].m + NB - 1) / NB);
   for (int jb = 0; jb < nblk; ++jb) {
@@ -503,12 +505,14 @@ int cholesky_aug_pair_async(nk_ctx* ctx, const CholSys* sys, int nsys) {
     NK_TRY(launch_gemm_pair(ctx, false, true, trail, nsys));
   }
   // backward on the extra rows E (extra x m, now holding (L^-1 R)^T):  E <- E L^-1
-  for (int jb = nblk - 1; jb >= 0; --jb) {
+  bool any_backward = false;
+  for (int q = 0; q < nsys; ++q) any_backward = any_backward || (sys[q].backward && sys[q].extra > 0);
+  for (int jb = nblk - 1; jb >= 0 && any_backward; --jb) {
     const int j0 = jb * NB;
     GemmCall diag[2], upd[2];
     for (int q = 0; q < nsys; ++q) {
       const CholSys& y = sys[q];
-      if (j0 >= y.m || y.extra <= 0) continue;
+      if (j0 >= y.m || y.extra <= 0 || !y.backward) continue;
       const int nbj = y.m - j0 < NB ? y.m - j0 : NB;
       double* E = y.P + (int64_t)y.m * y.ldp;
       const double* Li = y.Linv + (size_t)jb * NB * NB;
@@ -590,6 +594,202 @@ int cholesky_solve(nk_ctx* ctx, const double* L, int64_t ldl, int m, const doubl
   y.P = const_cast<double*>(L); y.ldp = ldl; y.m = m; y.Linv = const_cast<double*>(Linv); y.R = R; y.ldr = ldr;
   y.nrhs = nrhs;
   return cholesky_solve_pair(ctx, &y, 1);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// matrix square root through the polar decomposition of the Cholesky factor:  P = L L^T,  L^T = Q H  with Q orthogonal
+// and H = (L L^T)^{1/2} = P^{1/2}, hence  S = Q^T L^T  and  S^-1 = L^-T Q.   Q is the limit of the scaled Newton-Schulz
+// iteration  X <- X T,  T = s (3 I - s^2 X^T X) / 2,  X_0 = L^T / sqrt(||P||_inf): the eigenvalues of M = X^T X follow
+// exactly the map of the coupled iteration above (M_0 = P / c in both), so the step count is the same, but a step costs
+// one symmetric product (half the tiles) and ONE full product instead of two -- 3 m^3 flop instead of 5 m^3 -- and the
+// full product is a single 256-tile launch at m = 2000 that leaves every CU one workgroup slot for the factorisation
+// chain running beside it.  The price is one more latency-bound blocked Cholesky (with the identity riding along as
+// extra rows, which leaves L^-T), queued by sqrtm_prepare long before the iteration is needed.
+// ---------------------------------------------------------------------------------------------------------------
+// Xt = L * s on and below the diagonal, zero above (the factorisation leaves the old upper triangle in place);
+// X = Xt^T;  s = 1 / sqrt(d_c[0])
+__global__ void __launch_bounds__(256) tri_scale_both_kernel(const double* __restrict__ L, int64_t ldl, int m,
+                                                             const double* __restrict__ d_c, double* __restrict__ Xt,
+                                                             double* __restrict__ X) {
+  __shared__ double tile[32][33];
+  const double s = 1.0 / sqrt(d_c[0]);
+  const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int r = ty; r < 32; r += 8) {
+    const int i = by + r, j = bx + tx;
+    double v = 0.0;
+    if (i < m && j <= i) v = L[(int64_t)i * ldl + j] * s;
+    if (i < m && j < m) Xt[(int64_t)i * m + j] = v;
+    tile[r][tx] = v;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int i = bx + r, j = by + tx;
+    if (i < m && j < m) X[(int64_t)i * m + j] = tile[tx][r];
+  }
+}
+
+int sqrtm_prepare(nk_ctx* ctx, const double* P, int64_t ldp, int m, SqrtPlan* plan) {
+  plan->P = P; plan->ldp = ldp; plan->m = m;
+  plan->mark = arena_mark(ctx);
+  const size_t mm = (size_t)m * m;
+  const int nblk = (m + CHOL_NB - 1) / CHOL_NB;
+  NK_TRY(arena_alloc_t(ctx, 2 * mm, &plan->W));
+  NK_TRY(arena_alloc_t(ctx, (size_t)nblk * CHOL_NB * CHOL_NB, &plan->Linv));
+  NK_TRY(arena_alloc_t(ctx, mm, &plan->X0));
+  NK_TRY(arena_alloc_t(ctx, mm, &plan->X0t));
+  NK_TRY(arena_alloc_t(ctx, (size_t)8, &plan->d_sc));
+  NK_TRY(launch_max_abs_rowsum(ctx, P, ldp, m, plan->d_sc));
+  {
+    const ArenaMark mk = arena_mark(ctx);
+    const int blocks = grid_for((int64_t)m * m, ctx->num_cu);
+    double* partial = nullptr;
+    NK_TRY(arena_alloc_t(ctx, (size_t)2 * blocks, &partial));
+    hipLaunchKernelGGL(sumsq_trace_partial_kernel, dim3(blocks), dim3(256), 0, ctx->stream, P, ldp, m, partial, blocks);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, ctx->stream, partial, blocks, plan->d_sc + 1);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, ctx->stream, partial + blocks, blocks, plan->d_sc + 2);
+    NK_HIP(hipGetLastError());
+    arena_release(ctx, mk);
+  }
+  double* E = plan->W + mm;
+  NK_TRY(launch_copy2d(ctx, P, ldp, plan->W, m, m, m));
+  NK_TRY(launch_fill(ctx, E, m, m, m, 0.0));
+  NK_TRY(launch_add_diag(ctx, E, m, m, 1.0));
+  CholSys y;
+  y.P = plan->W; y.ldp = m; y.m = m; y.extra = m; y.backward = false; y.Linv = plan->Linv;
+  NK_TRY(cholesky_aug_pair_async(ctx, &y, 1));  // W <- [L ; L^-T]
+  const int tb = (m + 31) / 32;
+  hipLaunchKernelGGL(tri_scale_both_kernel, dim3(tb, tb), dim3(256), 0, ctx->stream, plan->W, (int64_t)m, m, plan->d_sc,
+                     plan->X0t, plan->X0);
+  NK_HIP(hipGetLastError());
+  return NK_OK;
+}
+
+int sqrtm_finish(nk_ctx* ctx, SqrtPlan* plan, double* S, double* Sinv, int* iters, double* resid) {
+  const int m = plan->m;
+  const size_t mm = (size_t)m * m;
+  const int ib = info_base(ctx);
+  NK_HIP(hipMemcpyAsync(ctx->h_scalars, plan->d_sc, 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  NK_HIP(hipMemcpyAsync(ctx->h_info + ib, ctx->d_info + ib, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  NK_HIP(hipStreamSynchronize(ctx->stream));
+  const double c = ctx->h_scalars[0], sumsq = ctx->h_scalars[1], trace = ctx->h_scalars[2];
+  if (ctx->h_info[ib] != 0 || !(c > 0.0) || !std::isfinite(c)) {
+    // not numerically positive definite for the Cholesky route (e.g. a rank-deficient kernel matrix with a jitter below
+    // the rounding level): the coupled iteration needs no factorisation
+    arena_release(ctx, plan->mark);
+    return sqrtm_spd_coupled(ctx, plan->P, plan->ldp, m, S, Sinv, iters, resid);
+  }
+  double *Xa = nullptr, *Xta = nullptr, *Xb = nullptr, *Xtb = nullptr, *M = nullptr, *T = nullptr;
+  NK_TRY(arena_alloc_t(ctx, mm, &Xa));
+  NK_TRY(arena_alloc_t(ctx, mm, &Xta));
+  NK_TRY(arena_alloc_t(ctx, mm, &Xb));
+  NK_TRY(arena_alloc_t(ctx, mm, &Xtb));
+  NK_TRY(arena_alloc_t(ctx, mm, &M));
+  NK_TRY(arena_alloc_t(ctx, mm, &T));
+  // spectrum interval [a, b] of M_0 = P / c, as in the coupled iteration: b = 1, a = mean of the eigenvalues other than
+  // the dominant one (an over-estimate of the smallest eigenvalue: the safe side)
+  double a_lo = 1.0, b_hi = 1.0;
+  {
+    const double fro = std::sqrt(sumsq) / c, tr = trace / c;
+    const double lam1 = fro < 1.0 ? fro : 1.0;
+    if (m > 1 && tr > lam1) a_lo = (tr - lam1) / (m - 1);
+    else a_lo = tr / m * 1e-2;
+    if (!(a_lo > 0.0) || !std::isfinite(a_lo)) a_lo = 1e-12;
+    if (a_lo > 1.0) a_lo = 1.0;
+  }
+  auto p3 = [](double x) { return x * (3.0 - x) * (3.0 - x) * 0.25; };
+  GemmOpts sym;
+  sym.tri = TRI_UPPER_MIRROR;
+  const double* X = plan->X0;
+  const double* Xt = plan->X0t;
+  double *Xn = Xa, *Xtn = Xta;
+  const int maxit = 100;
+  double r = 1e300;
+  int it = 0;
+  bool ok = false;
+  for (; it < maxit; ++it) {
+    if (it == 0) {
+      // M_0 = X_0^T X_0 = L L^T / c = P / c, taken as the average of P and P^T (no GEMM)
+      NK_TRY(launch_transpose(ctx, plan->P, plan->ldp, M, m, m, m));
+      NK_TRY(launch_axpby2d(ctx, 0.5 / c, plan->P, plan->ldp, 0.5 / c, M, m, m, m));
+    } else {
+      NK_TRY(launch_gemm(ctx, true, false, m, m, m, 1.0, X, m, X, m, 0.0, M, m, sym));  // M = X^T X
+    }
+    // Convergence checks (skipped during the growth phase, see the coupled iteration) do not stall the stream: the
+    // residual of M_k is reduced and copied asynchronously, step k is queued behind it, and only then does the host
+    // wait for the number -- the GPU is busy with the product of step k meanwhile.  A residual below 1e-7 means that
+    // X_{k+1} = X_k T_k (already queued) sits on the rounding floor (quadratic convergence), so it is the result.
+    const bool check = a_lo >= 0.5 || it + 2 >= maxit;
+    if (check) {
+      NK_TRY(launch_frob_minus_identity(ctx, M, m, m, ctx->d_scalars));
+      NK_HIP(hipMemcpyAsync(ctx->h_scalars, ctx->d_scalars, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+      NK_HIP(hipEventRecord(ctx->ev[10], ctx->stream));
+    }
+    const double s2 = 3.0 / (a_lo + std::sqrt(a_lo * b_hi) + b_hi);
+    const double sc = std::sqrt(s2);
+    {
+      const double xa = s2 * a_lo, xb = s2 * b_hi;
+      const double lo = p3(xa) < p3(xb) ? p3(xa) : p3(xb);
+      b_hi = (xa <= 1.0 && xb >= 1.0) ? 1.0 : (p3(xa) > p3(xb) ? p3(xa) : p3(xb));
+      a_lo = lo < b_hi ? lo : b_hi;
+    }
+    NK_TRY(launch_scale_add_identity(ctx, -0.5 * s2 * sc, M, m, 1.5 * sc, T, m, m));
+    {
+      // X T = (X^T)^T T on the TN engine; the epilogue also writes the transpose for the next step
+      TnProblem pr;
+      pr.A = Xt; pr.B = T; pr.C = Xn; pr.lda = pr.ldb = pr.ldc = m; pr.M = pr.N = m; pr.Ct = Xtn; pr.ldct = m;
+      if (tn_fast_ok(pr) && m >= 128) {
+        // one K slice while the tiles fill at most one workgroup slot per CU: the other slot stays free for the
+        // factorisation chain on the main stream (a two-slice launch would take every slot for its whole duration)
+        const int tiles = ((m + 127) / 128) * ((m + 127) / 128);
+        NK_TRY(launch_gemm_tn_multi(ctx, &pr, 1, m, tiles <= ctx->num_cu ? 1 : 0));
+      } else {
+        NK_TRY(launch_gemm(ctx, true, false, m, m, m, 1.0, Xt, m, T, m, 0.0, Xn, m));
+        NK_TRY(launch_transpose(ctx, Xn, m, Xtn, m, m, m));
+      }
+    }
+    X = Xn; Xt = Xtn;
+    Xn = (Xn == Xa) ? Xb : Xa;
+    Xtn = (Xtn == Xta) ? Xtb : Xta;
+    if (check) {
+      NK_HIP(hipEventSynchronize(ctx->ev[10]));
+      r = std::sqrt(ctx->h_scalars[0] / m);
+      if (!std::isfinite(r)) break;
+      if (r < 1e-7) {
+        ok = true;
+        ++it;
+        break;
+      }
+    }
+  }
+  if (iters) *iters = it;
+  if (resid) *resid = r;
+  if (!ok) {
+    set_error("sqrtm: Newton-Schulz did not converge (residual %g after %d iterations)", r, it);
+    arena_release(ctx, plan->mark);
+    return NK_ERR_NO_CONVERGENCE;
+  }
+  // S = Q^T L^T = sqrt(c) Q^T X_0 ;  S^-1 = L^-T Q = (L^-1)^T Q with L^-1 = (extra rows)^T
+  double* Linv_full = T;  // T is free now
+  NK_TRY(launch_transpose(ctx, plan->W + mm, m, Linv_full, m, m, m));
+  TnProblem pr[2];
+  pr[0].A = X; pr[0].B = plan->X0; pr[0].C = S; pr[0].lda = pr[0].ldb = pr[0].ldc = m; pr[0].M = pr[0].N = m;
+  pr[0].alpha = std::sqrt(c);
+  pr[1].A = Linv_full; pr[1].B = X; pr[1].C = Sinv; pr[1].lda = pr[1].ldb = pr[1].ldc = m; pr[1].M = pr[1].N = m;
+  if (tn_fast_ok(pr[0]) && tn_fast_ok(pr[1]) && m >= 128) {
+    NK_TRY(launch_gemm_tn_multi(ctx, pr, 2, m, 0));
+  } else {
+    NK_TRY(launch_gemm(ctx, true, false, m, m, m, pr[0].alpha, X, m, plan->X0, m, 0.0, S, m));
+    NK_TRY(launch_gemm(ctx, true, false, m, m, m, 1.0, Linv_full, m, X, m, 0.0, Sinv, m));
+  }
+  arena_release(ctx, plan->mark);
+  return NK_OK;
+}
+
+int sqrtm_spd(nk_ctx* ctx, const double* P, int64_t ldp, int m, double* S, double* Sinv, int* iters, double* resid) {
+  SqrtPlan plan;
+  NK_TRY(sqrtm_prepare(ctx, P, ldp, m, &plan));
+  return sqrtm_finish(ctx, &plan, S, Sinv, iters, resid);
 }
 
 }  // namespace nk
