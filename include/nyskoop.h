@@ -125,6 +125,11 @@ int nk_model_destroy(nk_model* model);
  *        'Z' m x d landmarks.   regressors.py:158-159,166,169. */
 int nk_model_get(nk_ctx* ctx, const nk_model* model, char which, double* out, int64_t ldo);
 int nk_model_dims(const nk_model* model, int32_t* m, int32_t* d, int32_t* p);
+/* all fitted operators in one call: G = [A B] (m x (m+p), the layout of regressors.py:157-159), C and W, copied
+ * concurrently on the context's streams (two DMA engines) when the outputs are host buffers.  Any of the three output
+ * pointers may be NULL. */
+int nk_model_get_ops(nk_ctx* ctx, const nk_model* model, double* G, int64_t ldg, double* C, int64_t ldc, double* W,
+                     int64_t ldw);
 
 /* ---- lift: replaces KoopmanNystromRegressor.lift (regressors.py:171-178) with K_mm^{-1/2} cached.
  *   Xq: nq x d query rows; out: nq x m (row i = phi(x_i); the reference returns the transpose, m x nq). ---- */

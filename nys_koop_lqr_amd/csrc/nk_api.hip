@@ -888,6 +888,31 @@ int nk_model_get(nk_ctx* ctx, const nk_model* mdl, char which, double* out, int6
   return NK_OK;
 }
 
+int nk_model_get_ops(nk_ctx* ctx, const nk_model* mdl, double* G, int64_t ldg, double* Cm, int64_t ldc, double* W,
+                     int64_t ldw) {
+  NK_TRY(check_ctx(ctx));
+  NK_REQUIRE(mdl != nullptr, "nk_model_get_ops: null model");
+  if (!mdl->has_ops) {
+    set_error("nk_model_get_ops: model holds no fitted operators");
+    return NK_ERR_BAD_ARG;
+  }
+  const int m = mdl->m, d = mdl->d, mp = m + mdl->p;
+  NK_REQUIRE((!G || ldg >= mp) && (!Cm || ldc >= m) && (!W || ldw >= mp), "nk_model_get_ops: leading dimension too small");
+  auto copy = [&](double* dst, int64_t ldd, const double* src, int64_t lds, int64_t rows, int64_t cols,
+                  hipStream_t st) -> hipError_t {
+    const hipMemcpyKind kind = is_device_ptr(dst) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    if (ldd == cols && lds == cols) return hipMemcpyAsync(dst, src, (size_t)rows * cols * 8, kind, st);
+    return hipMemcpy2DAsync(dst, (size_t)ldd * 8, src, (size_t)lds * 8, (size_t)cols * 8, (size_t)rows, kind, st);
+  };
+  // the big block on one stream, the two small ones on another: two DMA engines work at once
+  if (G) NK_HIP(copy(G, ldg, mdl->A, mp, m, mp, ctx->stream_main));
+  if (Cm) NK_HIP(copy(Cm, ldc, mdl->C, m, d, m, ctx->stream_side));
+  if (W) NK_HIP(copy(W, ldw, mdl->W, mp, d, mp, ctx->stream_side));
+  NK_HIP(hipStreamSynchronize(ctx->stream_side));
+  NK_HIP(hipStreamSynchronize(ctx->stream_main));
+  return NK_OK;
+}
+
 int nk_lift(nk_ctx* ctx, const nk_model* mdl, const double* Xq, int64_t ldx, int64_t nq, double* out, int64_t ldo) {
   NK_TRY(check_ctx(ctx));
   NK_REQUIRE(mdl && Xq && out, "nk_lift: null argument");

@@ -206,6 +206,8 @@ int cholesky_check_pair(nk_ctx* ctx, const CholSys* sys, int nsys);       // ver
 int cholesky_solve_pair(nk_ctx* ctx, const CholSys* sys, int nsys);
 int cholesky_aug_pair_async(nk_ctx* ctx, const CholSys* sys, int nsys);  // factor + both substitutions, no host sync
 constexpr int CHOL_NB = 64;
+// E_q <- E_q L_q^-1 on the extra rows of up to two factored systems, one launch (nk_trsm.hip)
+int launch_trsm_right_lower_pair(nk_ctx* ctx, const CholSys* sys, int nsys);
 
 // matrix-vector step of the lifted recursion for up to 8 trajectories (nk_rollout.hip)
 int launch_lifted_step(nk_ctx* ctx, const double* G, int64_t ldg, int m, int mz, int pu, const double* z, int64_t zstride,

@@ -463,8 +463,9 @@ int cholesky_lower_pair(nk_ctx* ctx, const CholSys* sys, int nsys) {
 }
 
 // Factorisation of [P; R^T] with the right-hand sides riding along as extra rows, then the backward substitution on
-// those rows.  Per block step: potrf (both systems), panel, trailing; then per block step of the backward pass two small
-// products.  The separate forward substitution (2 launches per block) disappears.
+// those rows.  Per block step: potrf (both systems), panel, trailing; the backward pass is a single launch in which
+// every workgroup carries a band of rows through the whole substitution.  The separate forward substitution
+// (2 launches per block) disappears.
 int cholesky_aug_pair_async(nk_ctx* ctx, const CholSys* sys, int nsys) {
   constexpr int NB = CHOL_NB;
   NK_REQUIRE(nsys >= 1 && nsys <= 2, "cholesky_aug_pair: 1..2 systems");
@@ -504,30 +505,8 @@ int cholesky_aug_pair_async(nk_ctx* ctx, const CholSys* sys, int nsys) {
     NK_TRY(launch_gemm_pair(ctx, false, true, panel, nsys));
     NK_TRY(launch_gemm_pair(ctx, false, true, trail, nsys));
   }
-  // backward on the extra rows E (extra x m, now holding (L^-1 R)^T):  E <- E L^-1
-  bool any_backward = false;
-  for (int q = 0; q < nsys; ++q) any_backward = any_backward || (sys[q].backward && sys[q].extra > 0);
-  for (int jb = nblk - 1; jb >= 0 && any_backward; --jb) {
-    const int j0 = jb * NB;
-    GemmCall diag[2], upd[2];
-    for (int q = 0; q < nsys; ++q) {
-      const CholSys& y = sys[q];
-      if (j0 >= y.m || y.extra <= 0 || !y.backward) continue;
-      const int nbj = y.m - j0 < NB ? y.m - j0 : NB;
-      double* E = y.P + (int64_t)y.m * y.ldp;
-      const double* Li = y.Linv + (size_t)jb * NB * NB;
-      // E_j <- E_j Linv_jj   (in place: one n-tile, every workgroup reads exactly the rows it writes)
-      diag[q].M = y.extra; diag[q].N = nbj; diag[q].K = nbj; diag[q].A = E + j0; diag[q].lda = y.ldp; diag[q].B = Li;
-      diag[q].ldb = NB; diag[q].C = E + j0; diag[q].ldc = y.ldp;
-      if (j0 > 0) {  // E[:, 0:j0] -= E_j L[j-block, 0:j0]
-        upd[q].M = y.extra; upd[q].N = j0; upd[q].K = nbj; upd[q].alpha = -1.0; upd[q].beta = 1.0;
-        upd[q].A = E + j0; upd[q].lda = y.ldp; upd[q].B = y.P + (int64_t)j0 * y.ldp; upd[q].ldb = y.ldp;
-        upd[q].C = E; upd[q].ldc = y.ldp;
-      }
-    }
-    NK_TRY(launch_gemm_pair(ctx, false, false, diag, nsys));
-    NK_TRY(launch_gemm_pair(ctx, false, false, upd, nsys));
-  }
+  // backward on the extra rows E (extra x m, now holding (L^-1 R)^T):  E <- E L^-1, one launch (nk_trsm.hip)
+  NK_TRY(launch_trsm_right_lower_pair(ctx, sys, nsys));
   return NK_OK;
 }
 

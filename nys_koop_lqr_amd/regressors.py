@@ -180,9 +180,8 @@ class KoopmanNystromRegressor(KoopmanRegressor):
         self.weights = _lib.pinned_empty((d, m + p))
         self.A = G[:, :m]  # views of G_ls, as in regressors.py:158-159
         self.B = G[:, m:]
-        for which, arr in (("A", self.A), ("B", self.B), ("C", self.C), ("W", self.weights)):
-            if arr.size:
-                _lib.check(ctx.lib.nk_model_get(ctx.handle, h, which.encode(), arr.ctypes.data, arr.strides[0] // 8))
+        _lib.check(ctx.lib.nk_model_get_ops(ctx.handle, h, G.ctypes.data, m + p, self.C.ctypes.data, m,
+                                            self.weights.ctypes.data, m + p))
         t_host3 = time.perf_counter()
         self._stats.update(host_ms_drop=(t_host1 - t_host0) * 1e3, host_ms_call=(t_host2 - t_host1) * 1e3,
                            host_ms_fetch=(t_host3 - t_host2) * 1e3)
