@@ -130,6 +130,13 @@ int nk_model_dims(const nk_model* model, int32_t* m, int32_t* d, int32_t* p);
  * pointers may be NULL. */
 int nk_model_get_ops(nk_ctx* ctx, const nk_model* model, double* G, int64_t ldg, double* C, int64_t ldc, double* W,
                      int64_t ldw);
+/* the same without waiting: returns once the copies are queued on the context's copy stream, so that they overlap with
+ * whatever the caller launches next (page-locked destination buffers, see nk_host_alloc, are needed for a true
+ * overlap).  The destinations must not be read before nk_model_wait(model) has returned; nk_model_destroy waits by
+ * itself.  One fetch per model is in flight at a time. */
+int nk_model_get_ops_async(nk_ctx* ctx, nk_model* model, double* G, int64_t ldg, double* C, int64_t ldc, double* W,
+                           int64_t ldw);
+int nk_model_wait(nk_model* model);
 
 /* ---- lift: replaces KoopmanNystromRegressor.lift (regressors.py:171-178) with K_mm^{-1/2} cached.
  *   Xq: nq x d query rows; out: nq x m (row i = phi(x_i); the reference returns the transpose, m x nq). ---- */

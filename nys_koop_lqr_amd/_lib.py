@@ -63,6 +63,8 @@ SIGNATURES = {
     "nk_model_get": (C.c_int, [_P, _P, C.c_char, _P, _I64]),
     "nk_model_dims": (C.c_int, [_P, C.POINTER(_I32), C.POINTER(_I32), C.POINTER(_I32)]),
     "nk_model_get_ops": (C.c_int, [_P, _P, _P, _I64, _P, _I64, _P, _I64]),
+    "nk_model_get_ops_async": (C.c_int, [_P, _P, _P, _I64, _P, _I64, _P, _I64]),
+    "nk_model_wait": (C.c_int, [_P]),
     "nk_lift": (C.c_int, [_P, _P, _P, _I64, _I64, _P, _I64]),
     "nk_predict": (C.c_int, [_P, _P, _P, _I64, _I64, _P, _I64]),
     "nk_score_neg_rmse": (C.c_int, [_P, _P, _P, _I64, _P, _I64, _I64, C.POINTER(_D)]),

@@ -377,6 +377,7 @@ int nk_create(int device, nk_ctx** out) {
   NK_HIP(hipStreamCreateWithPriority(&ctx->stream_main, hipStreamNonBlocking, prio_mid));
   NK_HIP(hipStreamCreateWithPriority(&ctx->stream_side, hipStreamNonBlocking, prio_lo));
   NK_HIP(hipStreamCreateWithPriority(&ctx->stream_prep, hipStreamNonBlocking, prio_hi));
+  NK_HIP(hipStreamCreateWithFlags(&ctx->stream_copy, hipStreamNonBlocking));
   ctx->stream = ctx->stream_main;
   ctx->cur_arena = &ctx->arena;
   NK_HIP(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
@@ -398,12 +399,14 @@ int nk_destroy(nk_ctx* ctx) {
   (void)hipStreamSynchronize(ctx->stream_main);
   (void)hipStreamSynchronize(ctx->stream_side);
   (void)hipStreamSynchronize(ctx->stream_prep);
+  (void)hipStreamSynchronize(ctx->stream_copy);
   for (auto& c : ctx->arena.chunks) (void)hipFree(c.base);
   for (auto& c : ctx->arena_side.chunks) (void)hipFree(c.base);
   (void)hipEventDestroy(ctx->ev_fork);
   (void)hipEventDestroy(ctx->ev_join);
   (void)hipStreamDestroy(ctx->stream_side);
   (void)hipStreamDestroy(ctx->stream_prep);
+  (void)hipStreamDestroy(ctx->stream_copy);
   (void)hipFree(ctx->d_info);
   (void)hipFree(ctx->d_scalars);
   if (ctx->d_zeros) (void)hipFree(ctx->d_zeros);
@@ -740,7 +743,10 @@ int nk_nystrom_fit(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int64
     // still on the side stream (the factorisation chain is usually not finished yet): S^-T and K_xo S^-1
     NK_TRY(launch_transpose(ctx, mdl->Sinv, m, Sinvt, m, m, m));
     if (same_centers) {
-      NK_TRY(launch_gemm(ctx, true, false, m, m, m, 1.0, Kxo, m, mdl->Sinv, m, 0.0, T1t, m));  // K(Z,Z) is bitwise symmetric
+      // K_xo = K_mm = S^2 - jitter I, hence K_xo S^-1 = S - jitter S^-1: no product (and a smaller rounding error than
+      // the product, whose terms are ||K|| ||S^-1|| large)
+      NK_TRY(launch_copy2d(ctx, mdl->S, m, T1t, m, m, m));
+      NK_TRY(launch_axpby2d(ctx, -jitter, mdl->Sinv, m, 1.0, T1t, m, m, m));
     } else {
       NK_TRY(launch_transpose(ctx, Kxo, m, X1, m, m, m));
       NK_TRY(launch_gemm(ctx, true, false, m, m, m, 1.0, X1, m, mdl->Sinv, m, 0.0, T1t, m));
@@ -847,6 +853,7 @@ int nk_model_create(nk_ctx* ctx, const nk_kernel_desc* kd, const double* Zout, i
 
 int nk_model_destroy(nk_model* model) {
   if (!model) return NK_OK;
+  (void)nk_model_wait(model);  // a pending asynchronous fetch still reads the buffers
   pool_give(model->device, model->bytes, model->buf);
   delete model;
   return NK_OK;
@@ -910,6 +917,55 @@ int nk_model_get_ops(nk_ctx* ctx, const nk_model* mdl, double* G, int64_t ldg, d
   if (W) NK_HIP(copy(W, ldw, mdl->W, mp, d, mp, ctx->stream_side));
   NK_HIP(hipStreamSynchronize(ctx->stream_side));
   NK_HIP(hipStreamSynchronize(ctx->stream_main));
+  return NK_OK;
+}
+
+int nk_model_get_ops_async(nk_ctx* ctx, nk_model* mdl, double* G, int64_t ldg, double* Cm, int64_t ldc, double* W,
+                           int64_t ldw) {
+  NK_TRY(check_ctx(ctx));
+  NK_REQUIRE(mdl != nullptr, "nk_model_get_ops_async: null model");
+  if (!mdl->has_ops) {
+    set_error("nk_model_get_ops_async: model holds no fitted operators");
+    return NK_ERR_BAD_ARG;
+  }
+  const int m = mdl->m, d = mdl->d, mp = m + mdl->p;
+  NK_REQUIRE((!G || ldg >= mp) && (!Cm || ldc >= m) && (!W || ldw >= mp),
+             "nk_model_get_ops_async: leading dimension too small");
+  NK_TRY(nk_model_wait(mdl));  // one fetch in flight per model
+  // everything that produced the operators was synchronised by the producing call (fit / model_create)
+  auto copy = [&](double* dst, int64_t ldd, const double* src, int64_t lds, int64_t rows, int64_t cols) -> hipError_t {
+    const hipMemcpyKind kind = is_device_ptr(dst) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    if (ldd == cols && lds == cols) return hipMemcpyAsync(dst, src, (size_t)rows * cols * 8, kind, ctx->stream_copy);
+    return hipMemcpy2DAsync(dst, (size_t)ldd * 8, src, (size_t)lds * 8, (size_t)cols * 8, (size_t)rows, kind,
+                            ctx->stream_copy);
+  };
+  if (G) NK_HIP(copy(G, ldg, mdl->A, mp, m, mp));
+  if (Cm) NK_HIP(copy(Cm, ldc, mdl->C, m, d, m));
+  if (W) NK_HIP(copy(W, ldw, mdl->W, mp, d, mp));
+  hipEvent_t ev = nullptr;
+  NK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  hipError_t e = hipEventRecord(ev, ctx->stream_copy);
+  if (e != hipSuccess) {
+    (void)hipEventDestroy(ev);
+    (void)hipStreamSynchronize(ctx->stream_copy);
+    set_error("hipEventRecord failed: %s", hipGetErrorString(e));
+    return NK_ERR_HIP;
+  }
+  mdl->ev_fetch = ev;
+  return NK_OK;
+}
+
+int nk_model_wait(nk_model* mdl) {
+  NK_REQUIRE(mdl != nullptr, "nk_model_wait: null model");
+  if (mdl->ev_fetch) {
+    hipError_t e = hipEventSynchronize(mdl->ev_fetch);
+    (void)hipEventDestroy(mdl->ev_fetch);
+    mdl->ev_fetch = nullptr;
+    if (e != hipSuccess) {
+      set_error("hipEventSynchronize failed: %s", hipGetErrorString(e));
+      return NK_ERR_HIP;
+    }
+  }
   return NK_OK;
 }
 

@@ -59,6 +59,7 @@ struct nk_ctx {
   hipStream_t stream = nullptr;       // CURRENT stream: every launcher uses this (swapped by nk::SideScope)
   hipStream_t stream_main = nullptr;
   hipStream_t stream_side = nullptr;  // second stream (lowest priority) for GEMM-bound work beside the main chain
+  hipStream_t stream_copy = nullptr;  // device->host copies of nk_model_get_ops_async (overlap with the next call's kernels)
   hipStream_t stream_prep = nullptr;  // third stream (highest priority) for small latency-bound work queued early: its
                                       // kernels must get CU slots while a big main-stream launch still has workgroups
                                       // pending (the dispatcher serves queues in strict priority order)
@@ -87,6 +88,7 @@ struct nk_model {
   double *A = nullptr, *B = nullptr, *C = nullptr, *W = nullptr, *S = nullptr, *Sinv = nullptr, *Z = nullptr,
          *winv = nullptr;  // winv: 1/lengthscale per dimension (d entries)
   bool has_ops = false;
+  hipEvent_t ev_fetch = nullptr;  // completion of the last nk_model_get_ops_async (nullptr: nothing pending)
 };
 
 namespace nk {
@@ -219,6 +221,7 @@ namespace nk {
 // ---- fast TN multi-problem GEMM (LDS-DMA staged), see nk_gemm_tn.hip -------------------------------------------
 // C_p[M_p x N_p] = alpha_p * A_p^T B_p + beta_p * C_p for up to 4 problems that share the contraction length K:
 // A_p stored K x M_p (lda), B_p stored K x N_p (ldb).  One launch covers every 128x128 tile of every problem.
+enum { KTRIM_NONE = 0, KTRIM_B_UPPER = 1 /* B (K x N) upper triangular */, KTRIM_A_LOWER = 2 /* A (K x M) lower triangular */ };
 struct TnProblem {
   const double* A = nullptr;
   const double* B = nullptr;
@@ -226,6 +229,7 @@ struct TnProblem {
   int64_t lda = 0, ldb = 0, ldc = 0;
   int M = 0, N = 0;
   int tri = TRI_FULL;  // TRI_UPPER_MIRROR for symmetric products (A == B)
+  int ktrim = 0;       // KTRIM_B_UPPER / KTRIM_A_LOWER: a triangular operand, the k range where it is zero is skipped
   double alpha = 1.0, beta = 0.0;
   double* Ct = nullptr;  // optional: also store the transpose, Ct[col][row] = C[row][col] (N x M, leading dim ldct)
   int64_t ldct = 0;

@@ -33,6 +33,7 @@ struct TnDev {
   int M, N;
   int tiles_n;     // tiles along N
   int tri;
+  int ktrim;       // KTRIM_*: skip the k range in which a triangular operand is zero
   int tile_begin;  // first global tile index of this problem
   double* C;       // direct epilogue (splitk == 1): C = alpha * acc + beta * C
   int64_t ldc;
@@ -99,8 +100,10 @@ __device__ __forceinline__ void tn_body(const TnParams& P) {
   }
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int kbeg = split * P.klen;
-  const int kend = min(P.K, kbeg + P.klen);
+  int kbeg = split * P.klen;
+  int kend = min(P.K, kbeg + P.klen);
+  if (pr.ktrim == KTRIM_B_UPPER) kend = min(kend, (tn + 1) * TBM);  // B[k][n] = 0 for k > n
+  if (pr.ktrim == KTRIM_A_LOWER) kbeg = max(kbeg, tm * TBM);        // A[k][i] = 0 for i > k
   const int ktiles = kend > kbeg ? (kend - kbeg + TBK - 1) / TBK : 0;
 
   // per-lane source columns (2 doubles per lane), clamped into the valid, 16-byte aligned range
@@ -384,7 +387,7 @@ int launch_gemm_tn_multi(nk_ctx* ctx, const TnProblem* probs, int nprob, int64_t
     const int tmn = (s.M + TBM - 1) / TBM, tnn = (s.N + TBM - 1) / TBM;
     TnDev& d = P.p[q];
     d.A = s.A; d.B = s.B; d.lda = s.lda; d.ldb = s.ldb; d.M = s.M; d.N = s.N;
-    d.tiles_n = tnn; d.tri = s.tri; d.tile_begin = ntiles;
+    d.tiles_n = tnn; d.tri = s.tri; d.ktrim = s.ktrim; d.tile_begin = ntiles;
     d.C = s.C; d.ldc = s.ldc; d.alpha = s.alpha; d.beta = s.beta; d.Ct = s.Ct; d.ldct = s.ldct;
     TnRed& r = R.p[q];
     r.Ct = s.Ct; r.ldct = s.ldct;
@@ -553,7 +556,7 @@ int launch_kmat_gram(nk_ctx* ctx, int ktype, const double* At, int64_t ldat, con
   const int tmn = (int)((nA + TBM - 1) / TBM), tnn = (int)((nB + TBM - 1) / TBM);
   TnDev& dv = P.p[0];
   dv.A = At; dv.B = Bt; dv.lda = ldat; dv.ldb = ldbt; dv.M = (int)nA; dv.N = (int)nB; dv.tiles_n = tnn; dv.tri = TRI_FULL;
-  dv.tile_begin = 0;
+  dv.tile_begin = 0; dv.ktrim = KTRIM_NONE;
   dv.C = nullptr; dv.ldc = 0; dv.alpha = 1.0; dv.beta = 0.0; dv.Ct = nullptr; dv.ldct = 0;
   for (int q = 1; q < TN_MAXP; ++q) { P.p[q] = P.p[0]; P.p[q].tile_begin = 1 << 30; }
   P.nprob = 1; P.ntiles = tmn * tnn; P.K = d; P.splitk = 1;

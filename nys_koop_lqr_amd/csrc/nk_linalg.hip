@@ -754,6 +754,8 @@ int sqrtm_finish(nk_ctx* ctx, SqrtPlan* plan, double* S, double* Sinv, int* iter
   TnProblem pr[2];
   pr[0].A = X; pr[0].B = plan->X0; pr[0].C = S; pr[0].lda = pr[0].ldb = pr[0].ldc = m; pr[0].M = pr[0].N = m;
   pr[0].alpha = std::sqrt(c);
+  pr[0].ktrim = KTRIM_B_UPPER;  // X_0 = L^T / sqrt(c) is upper triangular
+  pr[1].ktrim = KTRIM_A_LOWER;  // L^-1 is lower triangular
   pr[1].A = Linv_full; pr[1].B = X; pr[1].C = Sinv; pr[1].lda = pr[1].ldb = pr[1].ldc = m; pr[1].M = pr[1].N = m;
   if (tn_fast_ok(pr[0]) && tn_fast_ok(pr[1]) && m >= 128) {
     NK_TRY(launch_gemm_tn_multi(ctx, pr, 2, m, 0));

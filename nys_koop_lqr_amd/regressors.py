@@ -49,6 +49,23 @@ class KoopmanRegressor(BaseEstimator):
         return out.T
 
 
+def _fetched(name):
+    """Operator attribute of a fitted Nystrom regressor: `fit` queues the device->host copies and returns; the first
+    access waits for them (nk_model_wait), so a sweep that fits the next candidate right away overlaps the copies of
+    one fit with the kernels of the next."""
+    key = "_" + name
+
+    def get(self):
+        self._wait_fetch()
+        return self.__dict__.get(key)
+
+    def set_(self, value):
+        self._wait_fetch()
+        self.__dict__[key] = value
+
+    return property(get, set_)
+
+
 class KoopmanNystromRegressor(KoopmanRegressor):
     """regressors.py:114-178, MI355X-native.
 
@@ -58,7 +75,13 @@ class KoopmanNystromRegressor(KoopmanRegressor):
     the callers' inner loops (benchmark_lqr_cloth.py:18-36, 52-57, 69-104, 238-263) as single calls.
     """
 
+    A = _fetched("A")
+    B = _fetched("B")
+    C = _fetched("C")
+    weights = _fetched("weights")
+
     def __init__(self, n_inputs, kernel=None, gamma=None, m=None):
+        self._fetching = False
         super().__init__(n_inputs, gamma, m)
         self.kernel = kernel
         self.nystrom_centers_input = None
@@ -69,14 +92,24 @@ class KoopmanNystromRegressor(KoopmanRegressor):
         self._stats = None
 
     # ------------------------------------------------------------------------------------------------ plumbing
+    def _wait_fetch(self):
+        if self.__dict__.get("_fetching"):
+            self.__dict__["_fetching"] = False
+            _lib.check(_lib.load_library().nk_model_wait(self._model))
+
     def __getstate__(self):
+        self._wait_fetch()
         state = dict(self.__dict__)
         state["_model"] = None  # device handles never travel (benchmark_lqr_cloth.py:266-267 pickles regressors)
         state["_model_key"] = None
         return state
 
     def __setstate__(self, state):
+        for name in ("A", "B", "C", "weights"):  # states written before the operators became properties
+            if name in state:
+                state["_" + name] = state.pop(name)
         self.__dict__.update(state)
+        self.__dict__["_fetching"] = False
         self.__dict__.setdefault("_model", None)
         self.__dict__.setdefault("_model_key", None)
         self.__dict__.setdefault("_stats", None)
@@ -89,6 +122,7 @@ class KoopmanNystromRegressor(KoopmanRegressor):
 
     def _drop_model(self):
         if getattr(self, "_model", None):
+            self.__dict__["_fetching"] = False  # nk_model_destroy waits for a pending fetch itself
             _lib.load_library().nk_model_destroy(self._model)
             self._model = None
             self._model_key = None
@@ -98,9 +132,10 @@ class KoopmanNystromRegressor(KoopmanRegressor):
         replaced the landmarks / operators by hand."""
         if self.nystrom_centers_output is None:
             raise RuntimeError("regressor has no landmarks: call fit first")
-        key = (id(self.nystrom_centers_output), id(self.A), id(self.B), id(self.C), id(self.weights))
+        key = self._ops_key()
         if self._model is not None and self._model_key == key:
             return self._model
+        self._wait_fetch()
         self._drop_model()
         ctx = _lib.get_context()
         Z = np.ascontiguousarray(np.asarray(self.nystrom_centers_output, dtype=np.float64).T)  # m x d
@@ -176,16 +211,21 @@ class KoopmanNystromRegressor(KoopmanRegressor):
         self._model = h
         self._stats = stats.as_dict()
         G = _lib.pinned_empty((m, m + p))  # page-locked: the device->host copies run at the PCIe rate
-        self.C = _lib.pinned_empty((d, m))
-        self.weights = _lib.pinned_empty((d, m + p))
-        self.A = G[:, :m]  # views of G_ls, as in regressors.py:158-159
-        self.B = G[:, m:]
-        _lib.check(ctx.lib.nk_model_get_ops(ctx.handle, h, G.ctypes.data, m + p, self.C.ctypes.data, m,
-                                            self.weights.ctypes.data, m + p))
+        Cm = _lib.pinned_empty((d, m))
+        Wm = _lib.pinned_empty((d, m + p))
+        t_host2b = time.perf_counter()
+        self.__dict__.update(_A=G[:, :m], _B=G[:, m:], _C=Cm, _weights=Wm)  # A, B: views of G_ls (regressors.py:158-159)
+        _lib.check(ctx.lib.nk_model_get_ops_async(ctx.handle, h, G.ctypes.data, m + p, Cm.ctypes.data, m,
+                                                  Wm.ctypes.data, m + p))
+        self._fetching = True
         t_host3 = time.perf_counter()
         self._stats.update(host_ms_drop=(t_host1 - t_host0) * 1e3, host_ms_call=(t_host2 - t_host1) * 1e3,
-                           host_ms_fetch=(t_host3 - t_host2) * 1e3)
-        self._model_key = (id(self.nystrom_centers_output), id(self.A), id(self.B), id(self.C), id(self.weights))
+                           host_ms_fetch=(t_host3 - t_host2) * 1e3, host_ms_pinned=(t_host2b - t_host2) * 1e3)
+        self._model_key = self._ops_key()
+
+    def _ops_key(self):
+        d = self.__dict__
+        return (id(self.nystrom_centers_output), id(d.get("_A")), id(d.get("_B")), id(d.get("_C")), id(d.get("_weights")))
 
     # ------------------------------------------------------------------------------------------------ lift / predict
     def lift(self, X):
