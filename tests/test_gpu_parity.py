@@ -426,3 +426,77 @@ def test_cloth_known_answer_gain_and_closed_loop(nk, O, golden):
     xs, us = reg.closed_loop(K, phi0, phir, 60)
     xo, uo = O.lqr_closed_loop_lifted(reg.A, reg.B, reg.C, K, phi0, phir, 60)
     assert relf(xs, xo) < 1e-9 and relf(us, uo) < 1e-7
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# square root on the fast (LDS-DMA) path, numerically singular input, operator fetch forms
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("m", [256, 500])
+def test_sqrtm_fast_path_vs_scipy(nk, m):
+    """m >= 128 with an even leading dimension takes the LDS-DMA engine (triangular tile sets, transposed epilogue copies,
+    trimmed k ranges for the triangular factors); cond(P) ~ 1e8 like a jittered kernel matrix."""
+    from nys_koop_lqr_amd import _lib
+    import scipy.linalg
+    ctx = nk.get_context()
+    rng = np.random.default_rng(m)
+    pts = rng.standard_normal((m, 6))
+    D2 = ((pts[:, None, :] - pts[None, :, :]) ** 2).sum(-1)
+    P = np.exp(-0.5 * D2 / 9.0) + 1e-6 * np.eye(m)
+    S, Si = np.empty((m, m)), np.empty((m, m))
+    it, res = C.c_int32(), C.c_double()
+    _lib.check(ctx.lib.nk_sqrtm_spd(ctx.handle, P.ctypes.data, m, m, S.ctypes.data, Si.ctypes.data, C.byref(it), C.byref(res)))
+    ref = scipy.linalg.sqrtm(P).real
+    assert res.value < 1e-7 and 3 <= it.value < 40
+    assert relf(S, ref) < 1e-9 and relf(S @ S, P) < 1e-12
+    assert relf(Si @ P @ Si, np.eye(m)) < 1e-6 and relf(S, S.T) < 1e-11
+
+
+@pytest.mark.gpu
+def test_sqrtm_numerically_singular_input_is_handled(nk):
+    """A kernel matrix without jitter is numerically singular: the Cholesky route of the square root meets a
+    non-positive pivot and the coupled iteration takes over; either it delivers a square root or a clean error comes
+    back -- never a crash or a NaN result."""
+    from nys_koop_lqr_amd import _lib
+    ctx = nk.get_context()
+    m = 192
+    t = np.linspace(0.0, 1.0, m)
+    P = np.exp(-0.5 * (t[:, None] - t[None, :]) ** 2 / 0.5 ** 2)  # cond ~ 1e18
+    S, Si = np.empty((m, m)), np.empty((m, m))
+    rc = ctx.lib.nk_sqrtm_spd(ctx.handle, P.ctypes.data, m, m, S.ctypes.data, Si.ctypes.data, None, None)
+    if rc == 0:
+        assert np.all(np.isfinite(S)) and relf(S @ S, P) < 1e-6
+    else:
+        assert rc in (-3, -5) and ctx.lib.nk_last_error()
+
+
+@pytest.mark.gpu
+def test_operator_fetch_forms_agree(nk, O, golden):
+    """fit() queues the device->host copies (nk_model_get_ops_async) and the attributes wait on first access; the
+    blocking forms nk_model_get_ops / nk_model_get return the same bits."""
+    from nys_koop_lqr_amd import _lib
+    g = golden("f2_synth_rbf_d384.npz")
+    reg, X, Y, d = _fit(nk, O, "rbf", g, 6)
+    ctx = nk.get_context()
+    m, p = reg.A.shape[0], reg.B.shape[1]
+    assert not reg._fetching  # the access above waited
+    G, Cm, W = np.empty((m, m + p)), np.empty((d, m)), np.empty((d, m + p))
+    _lib.check(ctx.lib.nk_model_get_ops(ctx.handle, reg._model, G.ctypes.data, m + p, Cm.ctypes.data, m, W.ctypes.data, m + p))
+    assert np.array_equal(G[:, :m], reg.A) and np.array_equal(G[:, m:], reg.B)
+    assert np.array_equal(Cm, reg.C) and np.array_equal(W, reg.weights)
+    A1 = np.empty((m, m))
+    _lib.check(ctx.lib.nk_model_get(ctx.handle, reg._model, b"A", A1.ctypes.data, m))
+    assert np.array_equal(A1, reg.A)
+    # a strided destination (leading dimension > width) and NULL outputs
+    Gs = np.zeros((m, m + p + 3))
+    _lib.check(ctx.lib.nk_model_get_ops(ctx.handle, reg._model, Gs.ctypes.data, m + p + 3, None, 0, None, 0))
+    assert np.array_equal(Gs[:, : m + p], G) and not Gs[:, m + p:].any()
+    # operators replaced by hand: the device model is rebuilt from the host copies on the next use
+    before = reg.predict(X[:5])
+    reg.C = reg.C * 2.0
+    reg.weights = reg.weights * 2.0
+    assert relf(reg.predict(X[:5]), 2.0 * before) < 1e-12
+    # a second fit of the same object while the first fetch may still be in flight
+    reg.fit(X, Y)
+    reg.fit(X, Y)
+    assert relf(reg.predict(X[:5]), before) < 1e-9
