@@ -113,6 +113,25 @@ int nk_nystrom_fit(nk_ctx* ctx, const nk_kernel_desc* kd,
                    double gamma, double jitter,
                    nk_model** model, nk_fit_stats* stats);
 
+/* ---- the same fit split at its one exchange point, for SAMPLE-SHARDED fits over several GPUs: every
+ *   rank holds all landmarks and a slice of the rows, accumulates the four Gram blocks of its rows with nk_nystrom_gram
+ *   (regressors.py:151,153,162,164 without the regularisers), the packed accumulators are summed over the ranks (one
+ *   all-reduce of nk_gram_doubles(m,d,p) doubles: 102 MB at m=2000, d=384), and nk_nystrom_solve finishes the fit from the
+ *   sum (n_total = number of rows over all ranks, regressors.py:127).  gram: host or device memory; layout
+ *   [G1 (m+p)x(m+p) ; G2 m x (m+p)] row-major, then at the next even offset [G3 m x m ; G4 d x m].
+ *   nk_nystrom_gram followed by nk_nystrom_solve on one rank equals nk_nystrom_fit. ----------------------------------- */
+int nk_gram_doubles(int32_t m, int32_t d, int32_t p, int64_t* count);
+int nk_nystrom_gram(nk_ctx* ctx, const nk_kernel_desc* kd,
+                    const double* X, int64_t ldx, const double* Y, int64_t ldy,
+                    int64_t n, int32_t d, int32_t p,
+                    const int64_t* row_ranges, int32_t n_ranges,
+                    const double* Zin, int64_t ldzi, const double* Zout, int64_t ldzo, int32_t m,
+                    double* gram, nk_fit_stats* stats);
+int nk_nystrom_solve(nk_ctx* ctx, const nk_kernel_desc* kd,
+                     const double* Zin, int64_t ldzi, const double* Zout, int64_t ldzo, int32_t m, int32_t d, int32_t p,
+                     const double* gram, int64_t n_total, double gamma, double jitter,
+                     nk_model** model, nk_fit_stats* stats);
+
 /* rebuild a device model from host copies (un-pickling a regressor, benchmark_lqr_cloth.py:266-267 /
  * closed_loop_lqr_control.m:158-161); recomputes K_mm^{-1/2} from the landmarks once. A,B,C,W may be NULL. */
 int nk_model_create(nk_ctx* ctx, const nk_kernel_desc* kd, const double* Zout, int64_t ldz,

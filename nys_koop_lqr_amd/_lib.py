@@ -57,6 +57,11 @@ SIGNATURES = {
     "nk_nystrom_fit": (C.c_int, [_P, C.POINTER(KernelDesc), _P, _I64, _P, _I64, _I64, _I32, _I32,
                                  C.POINTER(_I64), _I32, _P, _I64, _P, _I64, _I32, _D, _D,
                                  C.POINTER(_P), C.POINTER(FitStats)]),
+    "nk_gram_doubles": (C.c_int, [_I32, _I32, _I32, C.POINTER(_I64)]),
+    "nk_nystrom_gram": (C.c_int, [_P, C.POINTER(KernelDesc), _P, _I64, _P, _I64, _I64, _I32, _I32,
+                                  C.POINTER(_I64), _I32, _P, _I64, _P, _I64, _I32, _P, C.POINTER(FitStats)]),
+    "nk_nystrom_solve": (C.c_int, [_P, C.POINTER(KernelDesc), _P, _I64, _P, _I64, _I32, _I32, _I32, _P, _I64, _D, _D,
+                                   C.POINTER(_P), C.POINTER(FitStats)]),
     "nk_model_create": (C.c_int, [_P, C.POINTER(KernelDesc), _P, _I64, _I32, _I32, _I32, _D, _P, _P, _P, _P,
                                   C.POINTER(_P)]),
     "nk_model_destroy": (C.c_int, [_P]),

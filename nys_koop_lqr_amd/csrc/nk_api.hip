@@ -468,21 +468,34 @@ int nk_kernel_matrix(nk_ctx* ctx, const nk_kernel_desc* kd, const double* A, int
   return NK_OK;
 }
 
-int nk_nystrom_fit(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int64_t ldx, const double* Y, int64_t ldy,
-                   int64_t n, int32_t d, int32_t p, const int64_t* row_ranges, int32_t n_ranges, const double* Zin,
-                   int64_t ldzi, const double* Zout, int64_t ldzo, int32_t m, double gamma, double jitter,
-                   nk_model** model, nk_fit_stats* stats) {
+// Packed Gram accumulator of a fit (nk_nystrom_gram / nk_nystrom_solve): [G1 (m+p)x(m+p) ; G2 m x (m+p)] row-major with
+// leading dimension m+p, then (at an even offset) [G3 m x m ; G4 d x m] with leading dimension m.
+static inline size_t gram_block1(int m, int p) { return (((size_t)(2 * m + p) * (m + p)) + 1) & ~(size_t)1; }
+static inline size_t gram_doubles(int m, int d, int p) { return gram_block1(m, p) + (size_t)(m + d) * m; }
+
+enum { FIT_FULL = 0, FIT_GRAM = 1, FIT_SOLVE = 2 };
+
+// One implementation for the three entry points: FIT_FULL (nk_nystrom_fit), FIT_GRAM (accumulate the Gram blocks of the
+// given rows into gram_io and stop), FIT_SOLVE (start from the accumulated Gram blocks in gram_io, n = total row count).
+static int fit_impl(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int64_t ldx, const double* Y, int64_t ldy,
+                    int64_t n, int32_t d, int32_t p, const int64_t* row_ranges, int32_t n_ranges, const double* Zin,
+                    int64_t ldzi, const double* Zout, int64_t ldzo, int32_t m, double gamma, double jitter,
+                    nk_model** model, nk_fit_stats* stats, int mode, double* gram_io) {
   HostTrace tr;
   NK_TRY(check_ctx(ctx));
   tr.mark("check_ctx/arena_reset");
-  NK_REQUIRE(kd && X && Y && Zout && model, "nk_nystrom_fit: null argument");
+  NK_REQUIRE(kd && Zout, "nk_nystrom_fit: null argument");
+  NK_REQUIRE(mode == FIT_SOLVE || (X && Y), "nk_nystrom_fit: null data pointer");
+  NK_REQUIRE(mode == FIT_GRAM || model != nullptr, "nk_nystrom_fit: null model pointer");
+  NK_REQUIRE(mode == FIT_FULL || gram_io != nullptr, "nk_nystrom_gram/solve: null accumulator");
   NK_REQUIRE(n > 0 && d > 0 && p >= 0 && m > 0, "nk_nystrom_fit: sizes must be positive (n=%lld d=%d p=%d m=%d)",
              (long long)n, d, p, m);
-  NK_REQUIRE(ldx >= d + p && ldy >= d && ldzo >= d, "nk_nystrom_fit: leading dimension too small");
+  NK_REQUIRE(mode == FIT_SOLVE || (ldx >= d + p && ldy >= d), "nk_nystrom_fit: leading dimension too small");
+  NK_REQUIRE(ldzo >= d, "nk_nystrom_fit: leading dimension too small");
   NK_REQUIRE(std::isfinite(gamma) && std::isfinite(jitter), "nk_nystrom_fit: gamma/jitter not finite");
-  *model = nullptr;
+  if (model) *model = nullptr;
   std::vector<int64_t> rng;
-  if (row_ranges && n_ranges > 0) {
+  if (mode != FIT_SOLVE && row_ranges && n_ranges > 0) {
     for (int i = 0; i < n_ranges; ++i) {
       const int64_t b = row_ranges[2 * i], e = row_ranges[2 * i + 1];
       NK_REQUIRE(0 <= b && b <= e && e <= n, "nk_nystrom_fit: row range %d = [%lld,%lld) outside [0,%lld)", i,
@@ -521,8 +534,10 @@ int nk_nystrom_fit(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int64
   NK_HIP(hipEventRecord(ev[0], ctx->stream));
   NK_TRY(make_winv(ctx, kd, d, mdl->winv));
   MatIn x, y, zi, zo;
-  NK_TRY(stage_in(ctx, X, ldx, n, d + p, &x));
-  NK_TRY(stage_in(ctx, Y, ldy, n, d, &y));
+  if (mode != FIT_SOLVE) {
+    NK_TRY(stage_in(ctx, X, ldx, n, d + p, &x));
+    NK_TRY(stage_in(ctx, Y, ldy, n, d, &y));
+  }
   NK_TRY(stage_in(ctx, Zout, ldzo, m, d, &zo));
   if (same_centers) zi = zo; else NK_TRY(stage_in(ctx, Zin, ldzi, m, d, &zi));
   NK_TRY(launch_copy2d(ctx, zo.ptr, zo.ld, mdl->Z, d, m, d));
@@ -531,6 +546,7 @@ int nk_nystrom_fit(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int64
 
   // ---- landmark kernels (regressors.py:139,143,144) -----------------------------------------------------------------
   double *Kmm = nullptr, *Kj = nullptr, *Kj_in = nullptr, *Kxo = nullptr;
+  if (mode != FIT_GRAM) {
   NK_TRY(arena_alloc_t(ctx, (size_t)m * m, &Kmm));
   NK_TRY(arena_alloc_t(ctx, (size_t)m * m, &Kj));
   NK_TRY(launch_kmat(ctx, kd->type, zo.ptr, zo.ld, m, zo.ptr, zo.ld, m, d, mdl->winv, kd->sigma0, Kmm, m));
@@ -547,6 +563,27 @@ int nk_nystrom_fit(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int64
     NK_TRY(launch_add_diag(ctx, Kj_in, m, m, jitter));
     NK_TRY(launch_kmat(ctx, kd->type, zi.ptr, zi.ld, m, zo.ptr, zo.ld, m, d, mdl->winv, kd->sigma0, Kxo, m));
   }
+  }
+  // Gram accumulators (regressors.py:151,153,162,164), one packed block (see gram_doubles):
+  //   G1 = Phi_in^T Phi_in (symmetric), G2 = Phi_out^T Phi_in (= cross), G3 = Phi_out^T Phi_out (symmetric),
+  //   G4 = Y^T Phi_out (= left_rec).  G2 sits directly below G1 and G4 below G3: the right-hand sides of the two
+  //   regularised systems ride along the blocked factorisations as extra rows (cholesky_aug_pair_async).
+  double *G1 = nullptr, *G2 = nullptr, *G3 = nullptr, *G4 = nullptr;
+  const int64_t ldd = d + (d & 1);
+  NK_TRY(arena_alloc_t(ctx, gram_doubles(m, d, p), &G1));
+  G2 = G1 + (size_t)mp * mp;
+  G3 = G1 + gram_block1(m, p);
+  G4 = G3 + (size_t)m * m;
+  float ms_gram_kernel = 0.f;
+  int gram_launches = 0;
+  bool gram_deferred = false;
+  const bool timed = stats != nullptr;
+  if (mode == FIT_SOLVE) {
+    // the accumulated Gram blocks come from the caller (host or device memory)
+    NK_HIP(hipMemcpyAsync(G1, gram_io, gram_doubles(m, d, p) * sizeof(double),
+                          is_device_ptr(gram_io) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
+    NK_HIP(hipEventRecord(ev[2], ctx->stream));
+  } else {
   // ---- feature matrix F = [K_nm_in | U | (pad) | K_nm_out], sample-major (regressors.py:141-142,147), built and
   //      contracted in PASSES of at most `pass_rows` rows so that the workspace stays bounded for very large n (the
   //      Gram accumulators are updated with beta = 1 from the second pass on); C4 (3.2 GB) is a single pass.
@@ -601,20 +638,6 @@ int nk_nystrom_fit(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int64
       NK_TRY(prep_rows(ctx, zi.ptr, zi.ld, m, d, mdl->winv, center, Zti, ldzt, sqzi));
     }
   }
-  // Gram accumulators (regressors.py:151,153,162,164):
-  //   G1 = Phi_in^T Phi_in (symmetric), G2 = Phi_out^T Phi_in (= cross), G3 = Phi_out^T Phi_out (symmetric),
-  //   G4 = Y^T Phi_out (= left_rec).  G2 sits directly below G1 and G4 below G3: the right-hand sides of the two
-  //   regularised systems ride along the blocked factorisations as extra rows (cholesky_aug_pair_async).
-  double *G1 = nullptr, *G2 = nullptr, *G3 = nullptr, *G4 = nullptr;
-  const int64_t ldd = d + (d & 1);
-  NK_TRY(arena_alloc_t(ctx, (size_t)(mp + m) * mp, &G1));
-  G2 = G1 + (size_t)mp * mp;
-  NK_TRY(arena_alloc_t(ctx, (size_t)(m + d) * m, &G3));
-  G4 = G3 + (size_t)m * m;
-  float ms_gram_kernel = 0.f;
-  int gram_launches = 0;
-  bool gram_deferred = false;
-  const bool timed = stats != nullptr;
   const bool multi_pass = passes.size() > 1;
   for (size_t ip = 0; ip < passes.size(); ++ip) {
     const std::vector<Piece>& ps = passes[ip];
@@ -688,7 +711,26 @@ int nk_nystrom_fit(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int64
       }
     }
   }
+  }  // mode != FIT_SOLVE
   NK_HIP(hipEventRecord(ev[3], ctx->stream));
+  if (mode == FIT_GRAM) {
+    // hand the accumulated blocks to the caller and stop (the model only carried the kernel parameters)
+    NK_HIP(hipMemcpyAsync(gram_io, G1, gram_doubles(m, d, p) * sizeof(double),
+                          is_device_ptr(gram_io) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
+    NK_HIP(hipStreamSynchronize(ctx->stream));
+    if (stats) {
+      memset(stats, 0, sizeof(*stats));
+      stats->ms_total = ev_ms(ctx, 0, 3);
+      stats->ms_upload = (x.staged || y.staged) ? ev_ms(ctx, 0, 1) : 0.0;
+      stats->ms_kmat = ev_ms(ctx, 1, 2);
+      stats->ms_gram = ev_ms(ctx, 2, 3);
+      if (gram_deferred) ms_gram_kernel = ev_ms(ctx, 14, 15);
+      stats->ms_gram_kernel_avg = gram_launches ? ms_gram_kernel / gram_launches : 0.0;
+      stats->gram_kernel_launches = gram_launches;
+    }
+    if (ctx->arena.chunks.size() > 1 || ctx->arena_side.chunks.size() > 1) NK_TRY(arena_reset(ctx));
+    return NK_OK;  // the guard returns the model buffers to the pool
+  }
   NK_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));  // the square-root iteration starts when the Gram launch is done
   tr.mark("gram issued");
 
@@ -803,6 +845,36 @@ int nk_nystrom_fit(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int64
   guard.m = nullptr;
   *model = mdl;
   return NK_OK;
+}
+
+int nk_nystrom_fit(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int64_t ldx, const double* Y, int64_t ldy,
+                   int64_t n, int32_t d, int32_t p, const int64_t* row_ranges, int32_t n_ranges, const double* Zin,
+                   int64_t ldzi, const double* Zout, int64_t ldzo, int32_t m, double gamma, double jitter,
+                   nk_model** model, nk_fit_stats* stats) {
+  NK_REQUIRE(model != nullptr, "nk_nystrom_fit: null argument");
+  return fit_impl(ctx, kd, X, ldx, Y, ldy, n, d, p, row_ranges, n_ranges, Zin, ldzi, Zout, ldzo, m, gamma, jitter, model,
+                  stats, FIT_FULL, nullptr);
+}
+
+int nk_gram_doubles(int32_t m, int32_t d, int32_t p, int64_t* count) {
+  NK_REQUIRE(count && m > 0 && d > 0 && p >= 0, "nk_gram_doubles: bad argument");
+  *count = (int64_t)gram_doubles(m, d, p);
+  return NK_OK;
+}
+
+int nk_nystrom_gram(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int64_t ldx, const double* Y, int64_t ldy,
+                    int64_t n, int32_t d, int32_t p, const int64_t* row_ranges, int32_t n_ranges, const double* Zin,
+                    int64_t ldzi, const double* Zout, int64_t ldzo, int32_t m, double* gram, nk_fit_stats* stats) {
+  return fit_impl(ctx, kd, X, ldx, Y, ldy, n, d, p, row_ranges, n_ranges, Zin, ldzi, Zout, ldzo, m, 0.0, 0.0, nullptr,
+                  stats, FIT_GRAM, gram);
+}
+
+int nk_nystrom_solve(nk_ctx* ctx, const nk_kernel_desc* kd, const double* Zin, int64_t ldzi, const double* Zout,
+                     int64_t ldzo, int32_t m, int32_t d, int32_t p, const double* gram, int64_t n_total, double gamma,
+                     double jitter, nk_model** model, nk_fit_stats* stats) {
+  NK_REQUIRE(model != nullptr, "nk_nystrom_solve: null argument");
+  return fit_impl(ctx, kd, nullptr, 0, nullptr, 0, n_total, d, p, nullptr, 0, Zin, ldzi, Zout, ldzo, m, gamma, jitter,
+                  model, stats, FIT_SOLVE, const_cast<double*>(gram));
 }
 
 int nk_model_create(nk_ctx* ctx, const nk_kernel_desc* kd, const double* Zout, int64_t ldz, int32_t m, int32_t d,

@@ -165,16 +165,11 @@ class KoopmanNystromRegressor(KoopmanRegressor):
         return h
 
     # ------------------------------------------------------------------------------------------------ fit
-    def fit(self, X, Y, row_ranges=None):
-        """regressors.py:122-169.  X: n x (d+p) rows [state | input], Y: n x d (NumPy arrays, or float64 device
-        tensors already resident in HBM).  Returns None, like the reference."""
-        ctx = _lib.get_context()
-        Xm, Ym = _lib.Mat(X), _lib.Mat(Y)
-        n, d = Ym.shape
-        p = int(self.n_inputs)
-        if Xm.shape != (n, d + p):
-            raise ValueError(f"X has shape {Xm.shape}, expected {(n, d + p)}")
+    def _prepare(self, n, d, Y=None):
+        """Landmarks (regressors.py:129-134) and kernel descriptor for a fit on d-dimensional states."""
         if self.nystrom_centers_output is None:  # regressors.py:129-132: global legacy NumPy RNG, n = #samples
+            if Y is None:
+                raise RuntimeError("landmarks must be set before a fit from Gram blocks")
             idx = np.random.choice(np.arange(0, n), size=self.m, replace=False)
             if _is_device_tensor(Y):
                 rows = Y[idx.tolist()]
@@ -184,29 +179,30 @@ class KoopmanNystromRegressor(KoopmanRegressor):
         if self.nystrom_centers_input is None:  # regressors.py:133-134
             self.nystrom_centers_input = self.nystrom_centers_output
         Zo = np.ascontiguousarray(np.asarray(self.nystrom_centers_output, dtype=np.float64).T)
-        m = Zo.shape[0]
         if Zo.shape[1] != d:
             raise ValueError(f"landmarks have dimension {Zo.shape[1]}, data has {d}")
         same = self.nystrom_centers_input is self.nystrom_centers_output
         Zi = Zo if same else np.ascontiguousarray(np.asarray(self.nystrom_centers_input, dtype=np.float64).T)
         kd, keep = self.kernel.kernel.desc(d)
-        rr, n_rr = None, 0
-        if row_ranges is not None:
-            flat = np.ascontiguousarray(np.asarray(row_ranges, dtype=np.int64).reshape(-1))
-            rr, n_rr = flat.ctypes.data_as(C.POINTER(C.c_int64)), flat.size // 2
-        stats = _lib.FitStats()
-        h = C.c_void_p()
-        t_host0 = time.perf_counter()
-        self._drop_model()
-        t_host1 = time.perf_counter()
-        rc = ctx.lib.nk_nystrom_fit(ctx.handle, C.byref(kd), Xm.ptr, Xm.ld, Ym.ptr, Ym.ld, n, d, p, rr, n_rr,
-                                    None if same else Zi.ctypes.data, d, Zo.ctypes.data, d, m,
-                                    float(self.gamma), float(self.jitter), C.byref(h), C.byref(stats))
+        return Zo, Zi, same, kd, keep
+
+    @staticmethod
+    def _ranges(row_ranges):
+        if row_ranges is None:
+            return None, 0, None
+        flat = np.ascontiguousarray(np.asarray(row_ranges, dtype=np.int64).reshape(-1))
+        return flat.ctypes.data_as(C.POINTER(C.c_int64)), flat.size // 2, flat
+
+    @staticmethod
+    def _raise(ctx, rc):
         if rc == -1:
             raise ValueError(ctx.lib.nk_last_error().decode())
         if rc == -3:
             raise np.linalg.LinAlgError(ctx.lib.nk_last_error().decode())
         _lib.check(rc)
+
+    def _adopt(self, ctx, h, stats, m, d, p, t_host):
+        """Take over a freshly fitted device model: queue the copies of the operators into page-locked arrays."""
         t_host2 = time.perf_counter()
         self._model = h
         self._stats = stats.as_dict()
@@ -219,9 +215,101 @@ class KoopmanNystromRegressor(KoopmanRegressor):
                                                   Wm.ctypes.data, m + p))
         self._fetching = True
         t_host3 = time.perf_counter()
-        self._stats.update(host_ms_drop=(t_host1 - t_host0) * 1e3, host_ms_call=(t_host2 - t_host1) * 1e3,
+        self._stats.update(host_ms_drop=(t_host[1] - t_host[0]) * 1e3, host_ms_call=(t_host2 - t_host[1]) * 1e3,
                            host_ms_fetch=(t_host3 - t_host2) * 1e3, host_ms_pinned=(t_host2b - t_host2) * 1e3)
         self._model_key = self._ops_key()
+
+    def fit(self, X, Y, row_ranges=None):
+        """regressors.py:122-169.  X: n x (d+p) rows [state | input], Y: n x d (NumPy arrays, or float64 device
+        tensors already resident in HBM).  Returns None, like the reference."""
+        ctx = _lib.get_context()
+        Xm, Ym = _lib.Mat(X), _lib.Mat(Y)
+        n, d = Ym.shape
+        p = int(self.n_inputs)
+        if Xm.shape != (n, d + p):
+            raise ValueError(f"X has shape {Xm.shape}, expected {(n, d + p)}")
+        Zo, Zi, same, kd, keep = self._prepare(n, d, Y)
+        m = Zo.shape[0]
+        rr, n_rr, keep_rr = self._ranges(row_ranges)
+        stats = _lib.FitStats()
+        h = C.c_void_p()
+        t_host0 = time.perf_counter()
+        self._drop_model()
+        t_host1 = time.perf_counter()
+        rc = ctx.lib.nk_nystrom_fit(ctx.handle, C.byref(kd), Xm.ptr, Xm.ld, Ym.ptr, Ym.ld, n, d, p, rr, n_rr,
+                                    None if same else Zi.ctypes.data, d, Zo.ctypes.data, d, m,
+                                    float(self.gamma), float(self.jitter), C.byref(h), C.byref(stats))
+        self._raise(ctx, rc)
+        self._adopt(ctx, h, stats, m, d, p, (t_host0, t_host1))
+
+    # ------------------------------------------------------------------------- sample-sharded fit (SURVEY 8e(2))
+    def gram_size(self, d):
+        """Number of float64 entries of the packed Gram accumulator for d-dimensional states."""
+        m = np.asarray(self.nystrom_centers_output).shape[1] if self.nystrom_centers_output is not None else int(self.m)
+        cnt = C.c_int64()
+        _lib.check(_lib.load_library().nk_gram_doubles(m, d, int(self.n_inputs), C.byref(cnt)))
+        return int(cnt.value)
+
+    def gram_partial(self, X, Y, row_ranges=None, out=None):
+        """The four Gram blocks of regressors.py:151,153,162,164 (without the regularisers) over the given rows only,
+        packed into one flat float64 buffer `out` (a NumPy array, or a 1-D device tensor which is then filled in
+        place without leaving the GPU).  Landmarks must be set: every shard of a sharded fit uses the same ones."""
+        ctx = _lib.get_context()
+        Xm, Ym = _lib.Mat(X), _lib.Mat(Y)
+        n, d = Ym.shape
+        p = int(self.n_inputs)
+        if Xm.shape != (n, d + p):
+            raise ValueError(f"X has shape {Xm.shape}, expected {(n, d + p)}")
+        if self.nystrom_centers_output is None:
+            raise RuntimeError("landmarks must be set before gram_partial (all shards share them)")
+        Zo, Zi, same, kd, keep = self._prepare(n, d)
+        m = Zo.shape[0]
+        cnt = self.gram_size(d)
+        if out is None:
+            out = np.empty(cnt)
+        if _is_device_tensor(out):
+            if out.dim() != 1 or out.numel() != cnt or not out.is_contiguous() or "float64" not in str(out.dtype):
+                raise ValueError(f"out must be a contiguous float64 tensor with {cnt} entries")
+            optr = out.data_ptr()
+        else:
+            if out.shape != (cnt,) or out.dtype != np.float64 or not out.flags.c_contiguous:
+                raise ValueError(f"out must be a contiguous float64 array with {cnt} entries")
+            optr = out.ctypes.data
+        rr, n_rr, keep_rr = self._ranges(row_ranges)
+        stats = _lib.FitStats()
+        rc = ctx.lib.nk_nystrom_gram(ctx.handle, C.byref(kd), Xm.ptr, Xm.ld, Ym.ptr, Ym.ld, n, d, p, rr, n_rr,
+                                     None if same else Zi.ctypes.data, d, Zo.ctypes.data, d, m, optr, C.byref(stats))
+        self._raise(ctx, rc)
+        self._gram_stats = stats.as_dict()
+        return out
+
+    def fit_from_gram(self, gram, n_total, d):
+        """Finish the fit from accumulated Gram blocks (the sum of gram_partial over all shards); n_total = number of
+        training rows over all shards (the `n` of regressors.py:127)."""
+        ctx = _lib.get_context()
+        p = int(self.n_inputs)
+        Zo, Zi, same, kd, keep = self._prepare(n_total, d)
+        m = Zo.shape[0]
+        cnt = self.gram_size(d)
+        if _is_device_tensor(gram):
+            if gram.numel() != cnt or not gram.is_contiguous() or "float64" not in str(gram.dtype):
+                raise ValueError(f"gram must be a contiguous float64 tensor with {cnt} entries")
+            gptr = gram.data_ptr()
+        else:
+            gram = np.ascontiguousarray(gram, dtype=np.float64).reshape(-1)
+            if gram.size != cnt:
+                raise ValueError(f"gram must have {cnt} entries")
+            gptr = gram.ctypes.data
+        stats = _lib.FitStats()
+        h = C.c_void_p()
+        t_host0 = time.perf_counter()
+        self._drop_model()
+        t_host1 = time.perf_counter()
+        rc = ctx.lib.nk_nystrom_solve(ctx.handle, C.byref(kd), None if same else Zi.ctypes.data, d, Zo.ctypes.data, d, m,
+                                      d, p, gptr, int(n_total), float(self.gamma), float(self.jitter), C.byref(h),
+                                      C.byref(stats))
+        self._raise(ctx, rc)
+        self._adopt(ctx, h, stats, m, d, p, (t_host0, t_host1))
 
     def _ops_key(self):
         d = self.__dict__

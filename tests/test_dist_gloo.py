@@ -64,3 +64,83 @@ def test_sharded_grid_search_world2_gloo(tmp_path):
         return O.cv_fold_score(mk, X, Y, fold, idx)
     serial = nkd.sharded_grid_search(g["X"], g["Y"], 6, cands, n_splits=5, unit_fn=unit, seed=7)
     assert np.allclose(serial["split_scores"], s0, rtol=1e-12, atol=0)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# sample-sharded single fit: plumbing of dist.sample_sharded_fit with the Gram blocks of the oracle
+# ---------------------------------------------------------------------------------------------------------------
+STUB = textwrap.dedent("""
+    import numpy as np
+    from oracle import nk_oracle as O
+
+    class StubRegressor:
+        '''gram_partial / fit_from_gram of the product class restated with the oracle's kernel (no GPU here).'''
+        def __init__(self, p, m, ls, d):
+            self.n_inputs, self.m = p, m
+            self.kern = O.ThreeDimensionalKernel(ls, ls, ls, d)
+            self.nystrom_centers_output = None
+            self.nystrom_centers_input = None
+            self.result = None
+        def gram_size(self, d):
+            m, p = self.m, self.n_inputs
+            return ((((2 * m + p) * (m + p)) + 1) & ~1) + (m + d) * m
+        def gram_partial(self, X, Y, row_ranges=None, out=None):
+            m, p, d = self.m, self.n_inputs, Y.shape[1]
+            Z = np.ascontiguousarray(self.nystrom_centers_output.T)
+            phi_in = np.hstack([self.kern.kernel(X[:, :d], Z), X[:, d:]])
+            phi_out = self.kern.kernel(Y, Z)
+            b1 = (((2 * m + p) * (m + p)) + 1) & ~1
+            out[:] = 0.0
+            out[: (2 * m + p) * (m + p)] = np.vstack([phi_in.T @ phi_in, phi_out.T @ phi_in]).ravel()
+            out[b1:] = np.vstack([phi_out.T @ phi_out, Y.T @ phi_out]).ravel()
+            return out
+        def fit_from_gram(self, gram, n_total, d):
+            self.result = (np.array(gram, copy=True), int(n_total), int(d))
+""")
+
+SHARD_WORKER = textwrap.dedent("""
+    import os, sys
+    import numpy as np
+    sys.path.insert(0, {root!r})
+    sys.path.insert(0, {out!r})
+    from nys_koop_lqr_amd import dist as nkd
+    from stub import StubRegressor
+    rank, world = nkd.init_process_group("gloo")
+    g = dict(np.load(os.path.join({root!r}, "tests", "golden", "f2_synth_rbf_d384.npz")))
+    X, Y = g["X"][:600], g["Y"][:600]
+    cut = 370                                   # uneven shards
+    lo, hi = (0, cut) if rank == 0 else (cut, 600)
+    reg = StubRegressor(6, 24, 20.0, Y.shape[1])
+    np.random.seed(3 if rank == 0 else 99)      # only rank 0's stream may matter
+    nkd.sample_sharded_fit(reg, X[lo:hi], Y[lo:hi])
+    gram, n_total, d = reg.result
+    np.savez(os.path.join({out!r}, f"shard_{{rank}}.npz"), gram=gram, n_total=n_total, Z=reg.nystrom_centers_output)
+""")
+
+
+def test_sample_sharded_fit_world2_gloo(tmp_path):
+    (tmp_path / "stub.py").write_text(STUB)
+    script = tmp_path / "worker.py"
+    script.write_text(SHARD_WORKER.format(root=ROOT, out=str(tmp_path)))
+    env = dict(os.environ, OMP_NUM_THREADS="2", OPENBLAS_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), str(script)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    a, b = np.load(tmp_path / "shard_0.npz"), np.load(tmp_path / "shard_1.npz")
+    assert int(a["n_total"]) == int(b["n_total"]) == 600
+    assert np.array_equal(a["Z"], b["Z"]) and np.array_equal(a["gram"], b["gram"])
+    # landmarks: rank 0's draw from the global legacy RNG over the concatenated rows (regressors.py:130)
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, str(tmp_path))
+    from stub import StubRegressor
+    g = dict(np.load(os.path.join(ROOT, "tests", "golden", "f2_synth_rbf_d384.npz")))
+    X, Y = g["X"][:600], g["Y"][:600]
+    np.random.seed(3)
+    idx = np.random.choice(np.arange(0, 600), size=24, replace=False)
+    assert np.array_equal(a["Z"], Y[idx].T)
+    # the all-reduced accumulator equals the Gram blocks of the whole data set
+    full = StubRegressor(6, 24, 20.0, Y.shape[1])
+    full.nystrom_centers_output = Y[idx].T
+    ref = full.gram_partial(X, Y, out=np.empty(full.gram_size(Y.shape[1])))
+    assert np.max(np.abs(a["gram"] - ref)) <= 1e-12 * np.max(np.abs(ref))

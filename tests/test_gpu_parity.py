@@ -1,6 +1,7 @@
 """GPU parity tests proper: the HIP path (through the C-ABI, ctypes) against the CPU oracle on the same seeded
 inputs and against the committed golden vectors produced by the reference.  Run with `-m gpu` on an MI355X."""
 import ctypes as C
+import os
 import pickle
 
 import numpy as np
@@ -500,3 +501,90 @@ def test_operator_fetch_forms_agree(nk, O, golden):
     reg.fit(X, Y)
     reg.fit(X, Y)
     assert relf(reg.predict(X[:5]), before) < 1e-9
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# sample-sharded fit: Gram blocks of row shards, summed, then the O(m^3) stage from the sum
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_gram_partial_plus_solve_equals_fit(nk, O, golden):
+    import torch
+    g = golden("f2_synth_rbf_d384.npz")
+    reg, X, Y, d = _fit(nk, O, "rbf", g, 6)
+    n = X.shape[0]
+    ref = dict(A=reg.A.copy(), B=reg.B.copy(), C=reg.C.copy(), W=reg.weights.copy())
+
+    def twin():
+        kern, _ = _kernels(nk, O, "rbf", g["ls"], d)
+        r = nk.KoopmanNystromRegressor(6, kernel=kern, gamma=float(g["gamma"]), m=len(g["idx"]))
+        r.nystrom_centers_output = Y.T[:, g["idx"]]
+        return r
+
+    # one shard = the whole data set: the split entry points reproduce the fused fit
+    a = twin()
+    gram = a.gram_partial(X, Y)
+    assert gram.shape == (a.gram_size(d),)
+    a.fit_from_gram(gram, n, d)
+    for k, got in (("A", a.A), ("B", a.B), ("C", a.C), ("W", a.weights)):
+        assert relf(got, ref[k]) < 1e-12, k
+    # three uneven shards (host arrays, row ranges of one array, a device-resident shard with a device accumulator)
+    cuts = [0, n // 3 + 5, 2 * n // 3 - 11, n]
+    b = twin()
+    total = b.gram_partial(X[cuts[0]:cuts[1]], Y[cuts[0]:cuts[1]])
+    total = total + b.gram_partial(X, Y, row_ranges=[(cuts[1], cuts[2])])
+    dev = torch.device("cuda", 0)
+    acc = torch.zeros(b.gram_size(d), dtype=torch.float64, device=dev)
+    b.gram_partial(torch.from_numpy(X[cuts[2]:]).to(dev), torch.from_numpy(Y[cuts[2]:]).to(dev), out=acc)
+    acc += torch.from_numpy(total).to(dev)
+    b.fit_from_gram(acc, n, d)  # device pointer straight into the library
+    for k, got in (("A", b.A), ("B", b.B), ("C", b.C), ("W", b.weights)):
+        assert relf(got, ref[k]) < 1e-9, k  # summation order over the samples differs
+    assert relf(b.predict(X[:7]), reg.predict(X[:7])) < 1e-10
+    with pytest.raises(ValueError):
+        b.fit_from_gram(total[:-1], n, d)
+
+
+SHARD_GPU_WORKER = """
+import os, sys
+import numpy as np
+sys.path.insert(0, {root!r})
+import nys_koop_lqr_amd as nk
+from nys_koop_lqr_amd import dist as nkd
+rank, world = nkd.init_process_group("gloo")   # two ranks sharing the one GPU of the test box: host-side all-reduce
+g = dict(np.load(os.path.join({root!r}, "tests", "golden", "f2_synth_rbf_d384.npz")))
+X, Y = g["X"].astype(np.float64), g["Y"].astype(np.float64)
+n, d = Y.shape
+cut = n // 2 + 37
+lo, hi = (0, cut) if rank == 0 else (cut, n)
+ls = np.ravel(g["ls"])
+l3 = ls if ls.size == 3 else np.repeat(ls, 3)
+reg = nk.KoopmanNystromRegressor(6, kernel=nk.ThreeDimensionalKernel(*l3, d), gamma=float(g["gamma"]), m=len(g["idx"]))
+nkd.sample_sharded_fit(reg, X[lo:hi], Y[lo:hi], landmark_rows=g["idx"])
+np.savez(os.path.join({out!r}, f"fit_{{rank}}.npz"), A=reg.A, B=reg.B, C=reg.C, W=reg.weights, Z=reg.nystrom_centers_output)
+"""
+
+
+@pytest.mark.gpu
+def test_sample_sharded_fit_two_ranks_one_gpu(nk, O, golden, tmp_path):
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "worker.py"
+    script.write_text(SHARD_GPU_WORKER.format(root=root, out=str(tmp_path)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), str(script)]
+    env = dict(os.environ, NYSKOOP_DEVICE="0")  # both ranks on the one GPU of the test box
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    f0, f1 = np.load(tmp_path / "fit_0.npz"), np.load(tmp_path / "fit_1.npz")
+    g = golden("f2_synth_rbf_d384.npz")
+    reg, X, Y, d = _fit(nk, O, "rbf", g, 6)
+    assert np.array_equal(f0["Z"], reg.nystrom_centers_output) and np.array_equal(f0["Z"], f1["Z"])
+    for k, ref in (("A", reg.A), ("B", reg.B), ("C", reg.C), ("W", reg.weights)):
+        assert np.array_equal(f0[k], f1[k]), k      # both ranks solve from the same summed accumulator
+        assert relf(f0[k], ref) < 1e-9, k
