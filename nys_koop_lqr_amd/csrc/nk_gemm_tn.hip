@@ -491,16 +491,29 @@ __global__ void __launch_bounds__(256) prep_rows_kernel(const double* __restrict
     if (k < d && row < rows) Xt[(int64_t)k * ldt + row] = tile[tx][r];
   }
 }
+// squared norms of the columns of Xt (d x rows): 64 columns per workgroup, the d rows dealt to the four waves
+// (coalesced 512-byte row segments, four loads in flight per lane), fixed-order sum of the four partials
 __global__ void __launch_bounds__(256) colsq_kernel(const double* __restrict__ Xt, int64_t ldt, int rows, int d,
                                                     double* __restrict__ sq) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= rows) return;
-  double s = 0.0;
-  for (int k = 0; k < d; ++k) {
-    const double v = Xt[(int64_t)k * ldt + i];
-    s = fma(v, v, s);
+  __shared__ double part[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + lane;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  if (i < rows) {
+    int k = w;
+    for (; k + 12 < d; k += 16) {
+      const double v0 = Xt[(int64_t)k * ldt + i], v1 = Xt[(int64_t)(k + 4) * ldt + i];
+      const double v2 = Xt[(int64_t)(k + 8) * ldt + i], v3 = Xt[(int64_t)(k + 12) * ldt + i];
+      s0 = fma(v0, v0, s0); s1 = fma(v1, v1, s1); s2 = fma(v2, v2, s2); s3 = fma(v3, v3, s3);
+    }
+    for (; k < d; k += 4) {
+      const double v = Xt[(int64_t)k * ldt + i];
+      s0 = fma(v, v, s0);
+    }
   }
-  sq[i] = s;
+  part[w][lane] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (w == 0 && i < rows) sq[i] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
 }
 // column means in two deterministic passes: per-chunk partial sums (coalesced across columns), then a fixed-order sum
 __global__ void __launch_bounds__(256) colsum_partial_kernel(const double* __restrict__ Z, int64_t ldz, int rows, int d,
@@ -540,7 +553,7 @@ int prep_rows(nk_ctx* ctx, const double* X, int64_t ldx, int64_t rows, int d, co
               double* Xt, int64_t ldt, double* sq) {
   dim3 grid((d + 31) / 32, (unsigned)((rows + 31) / 32));
   hipLaunchKernelGGL(prep_rows_kernel, grid, dim3(256), 0, ctx->stream, X, ldx, (int)rows, d, winv, center, Xt, ldt);
-  hipLaunchKernelGGL(colsq_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, ctx->stream, Xt, ldt, (int)rows, d, sq);
+  hipLaunchKernelGGL(colsq_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(256), 0, ctx->stream, Xt, ldt, (int)rows, d, sq);
   NK_HIP(hipGetLastError());
   return NK_OK;
 }

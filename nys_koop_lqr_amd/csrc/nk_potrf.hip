@@ -69,6 +69,7 @@ __global__ void __launch_bounds__(64) potrf_diag_kernel(PotrfBatch pb, int blk) 
   __shared__ double As[NB * PLD];
   __shared__ double Iv[NB * PLD];
   __shared__ double Sc[3 * 16 * SLD];
+  __shared__ double dinv[NB];  // 1 / L_kk
   const int lane = threadIdx.x;
   const int l15 = lane & 15, l4 = lane >> 4;
   // whole rows are loaded (the upper triangle is carried along but never consumed); rows / columns beyond nb are
@@ -95,8 +96,15 @@ __global__ void __launch_bounds__(64) potrf_diag_kernel(PotrfBatch pb, int blk) 
         if (lane == 0 && c0 + k < nb) atomicCAS(info, 0, blk * NB + c0 + k + 1);
         dkk = 1.0;
       }
-      const double s = sqrt(dkk);
-      const double inv = 1.0 / s;
+      // sqrt and reciprocal without the library routines (about 45 dependent fp64 VALU instructions per pivot between
+      // them, more than the whole panel update): hardware rsq seed, two Newton steps, one Heron correction
+      double inv = __builtin_amdgcn_rsq(dkk);
+      inv = inv * fma(-0.5 * dkk * inv, inv, 1.5);
+      inv = inv * fma(-0.5 * dkk * inv, inv, 1.5);
+      double s = dkk * inv;
+      s = fma(0.5 * inv, fma(-s, s, dkk), s);   // s = sqrt(dkk) to the last bit or two
+      inv = fma(inv, fma(-s, inv, 1.0), inv);   // inv = 1 / s
+      if (lane == c0 + k) dinv[c0 + k] = inv;
       R[k] = (lane == c0 + k) ? s : R[k] * inv;  // lanes > c0+k: L[i][c0+k]; lanes above hold unused upper-triangle values
       // R[jj] -= L[i][c0+k] * L[c0+jj][c0+k]; the second factor is lane c0+jj's R[k]: readlane -> SGPR pair -> scalar
       // operand of the FMA, kept in ONE asm statement (hipcc otherwise hoists the readlanes and spills the SGPRs)
@@ -151,7 +159,7 @@ __global__ void __launch_bounds__(64) potrf_diag_kernel(PotrfBatch pb, int blk) 
         if ((j & 1) == 0) s0 = fma(-l, x[j], s0);
         else s1 = fma(-l, x[j], s1);
       }
-      x[i] = (s0 + s1) / Lb[i * PLD + i];
+      x[i] = (s0 + s1) * dinv[16 * l4 + i];
     }
     double* Db = Iv + (16 * l4) * PLD + 16 * l4;
 #pragma unroll
