@@ -780,7 +780,7 @@ static int fit_impl(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int6
     NK_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_fork, 0));
     NK_HIP(hipStreamWaitEvent(ctx->stream, ev[9], 0));
     NK_HIP(hipEventRecord(ev[6], ctx->stream));
-    NK_TRY(sqrtm_finish(ctx, &splan, mdl->S, mdl->Sinv, &it, &resid));
+    NK_TRY(sqrtm_finish(ctx, &splan, mdl->S, mdl->Sinv));
     NK_HIP(hipEventRecord(ev[7], ctx->stream));
     // still on the side stream (the factorisation chain is usually not finished yet): S^-T and K_xo S^-1
     NK_TRY(launch_transpose(ctx, mdl->Sinv, m, Sinvt, m, m, m));
@@ -816,6 +816,7 @@ static int fit_impl(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int6
   tr.mark("solve issued");
   NK_HIP(hipStreamSynchronize(ctx->stream));
   tr.mark("final sync");
+  NK_TRY(sqrtm_verdict(ctx, &splan, &it, &resid));  // the iteration was queued without host round trips
   mdl->has_ops = true;
 
   if (stats) {

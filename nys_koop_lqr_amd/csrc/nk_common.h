@@ -177,11 +177,19 @@ struct SqrtPlan {
   double* Linv = nullptr;  // inverted diagonal blocks
   double* X0 = nullptr;    // L^T / sqrt(c)   (c = ||P||_inf)
   double* X0t = nullptr;   // L / sqrt(c)
-  double* d_sc = nullptr;  // device scalars: c, ||P||_F^2, trace(P)
+  double* d_sc = nullptr;  // device scalars: c, ||P||_F^2, trace(P), ||L^-1||_F^2; then the iteration state
+                           // [5] convergence flag (step + 1), [6] residual at that step, [7] last residual
   ArenaMark mark{0, 0};
+  // verdict of sqrtm_finish: known at once for the synchronous forms, otherwise in ctx->h_scalars[8..10] once the
+  // stream has been synchronised (sqrtm_verdict)
+  bool deferred = false;
+  int rc = 0, iters = 0, kmax = 0;
+  double resid = 0.0;
 };
 int sqrtm_prepare(nk_ctx* ctx, const double* P, int64_t ldp, int m, SqrtPlan* plan);
-int sqrtm_finish(nk_ctx* ctx, SqrtPlan* plan, double* S, double* Sinv, int* iters, double* resid);
+int sqrtm_finish(nk_ctx* ctx, SqrtPlan* plan, double* S, double* Sinv);
+// after the stream that ran sqrtm_finish has been synchronised: NK_OK / NK_ERR_NO_CONVERGENCE, iteration count, residual
+int sqrtm_verdict(nk_ctx* ctx, SqrtPlan* plan, int* iters, double* resid);
 // in-place lower Cholesky of P (m x m, ld), Linv workspace holds inverted diagonal blocks
 int cholesky_lower(nk_ctx* ctx, double* P, int64_t ldp, int m, double* Linv /* nblk*NB*NB */);
 int cholesky_solve(nk_ctx* ctx, const double* L, int64_t ldl, int m, const double* Linv, double* R, int64_t ldr,
@@ -233,10 +241,19 @@ struct TnProblem {
   double alpha = 1.0, beta = 0.0;
   double* Ct = nullptr;  // optional: also store the transpose, Ct[col][row] = C[row][col] (N x M, leading dim ldct)
   int64_t ldct = 0;
+  const double* pass = nullptr;  // conditional launches (TnSkip): matrix copied to C / Ct when the launch is skipped
+  int64_t ldpass = 0;
+};
+// Device-side condition of a launch: skipped when state[0] != 0 && state[0] <= step (single-slice launches then copy
+// `pass` to the outputs, split-K launches and their reduce just return).  Lets an iteration with a data-dependent length
+// be queued in full without host round trips.
+struct TnSkip {
+  const double* state;
+  int step;
 };
 bool tn_fast_ok(const TnProblem& p);  // alignment / leading-dimension requirements of the LDS-DMA path
 int launch_gemm_tn_multi(nk_ctx* ctx, const TnProblem* probs, int nprob, int64_t K, int splitk /*0=auto*/,
-                         float* ms_kernel = nullptr, bool sync_timing = true);
+                         float* ms_kernel = nullptr, bool sync_timing = true, const TnSkip* skip = nullptr);
 int launch_transpose(nk_ctx* ctx, const double* src, int64_t lds, double* dst, int64_t ldd, int rows, int cols);
 // Gram-form kernel matrix on the MFMA engine (nk_gemm_tn.hip): prep_rows centres/scales/transposes rows to
 // contraction-major and returns their squared norms; launch_kmat_gram evaluates k() in the GEMM epilogue

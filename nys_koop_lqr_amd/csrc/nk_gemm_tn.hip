@@ -40,6 +40,8 @@ struct TnDev {
   double alpha, beta;
   double* Ct;      // optional transposed copy of the result
   int64_t ldct;
+  const double* pass;  // conditional launches: when the launch is skipped, C (and Ct) receive this matrix instead
+  int64_t ldpass;
 };
 struct TnParams {
   TnDev p[TN_MAXP];
@@ -48,6 +50,10 @@ struct TnParams {
   int K, splitk, klen;
   const double* zeros;  // >= 1 KiB of zeros
   double* slab;
+  // conditional launch (device-side early exit of an iteration that has already converged, no host round trip): the
+  // launch is skipped when skip_state[0] != 0 && skip_state[0] <= skip_step
+  const double* skip_state;
+  int skip_step;
   // fused kernel-matrix epilogue (EPI == 1): out[i][j] = k(sqa[i] + sqb[j] - 2 acc)
   const double* sqa;
   const double* sqb;
@@ -100,6 +106,22 @@ __device__ __forceinline__ void tn_body(const TnParams& P) {
   }
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (EPI == 0 && P.skip_state != nullptr) {
+    const double f = P.skip_state[0];
+    if (f != 0.0 && f <= (double)P.skip_step) {
+      if (pr.pass != nullptr && P.splitk == 1) {  // pass the previous iterate through: C = pass (and Ct = pass^T)
+        for (int e = threadIdx.x; e < TBM * TBM; e += 256) {
+          const int row = tm * TBM + (e >> 7), col = tn * TBM + (e & 127);
+          if (row < pr.M && col < pr.N) {
+            const double v = pr.pass[(int64_t)row * pr.ldpass + col];
+            pr.C[(int64_t)row * pr.ldc + col] = v;
+            if (pr.Ct) pr.Ct[(int64_t)col * pr.ldct + row] = v;
+          }
+        }
+      }
+      return;
+    }
+  }
   int kbeg = split * P.klen;
   int kend = min(P.K, kbeg + P.klen);
   if (pr.ktrim == KTRIM_B_UPPER) kend = min(kend, (tn + 1) * TBM);  // B[k][n] = 0 for k > n
@@ -255,6 +277,8 @@ struct TnRedParams {
   TnRed p[TN_MAXP];
   int nprob, splitk;
   const double* slab;
+  const double* skip_state;  // see TnParams
+  int skip_step;
 };
 
 // C = alpha * sum_s slab[tile][s] + beta * C (bounds, mirror, transposed copy).  RPARTS workgroups per tile, each summing
@@ -263,6 +287,10 @@ struct TnRedParams {
 constexpr int RPARTS = 8;
 __global__ void __launch_bounds__(256) gemm_tn_reduce_kernel(TnRedParams P) {
   __shared__ double sh[16][130];
+  if (P.skip_state != nullptr) {
+    const double f = P.skip_state[0];
+    if (f != 0.0 && f <= (double)P.skip_step) return;
+  }
   const int gt = blockIdx.x / RPARTS, part = blockIdx.x % RPARTS;
   int pi = 0;
 #pragma unroll
@@ -373,7 +401,7 @@ static int ensure_zero_page(nk_ctx* ctx) {
 }
 
 int launch_gemm_tn_multi(nk_ctx* ctx, const TnProblem* probs, int nprob, int64_t K, int splitk, float* ms_kernel,
-                         bool sync_timing) {
+                         bool sync_timing, const TnSkip* skip) {
   NK_REQUIRE(nprob >= 1 && nprob <= TN_MAXP, "gemm_tn_multi: 1..4 problems");
   NK_REQUIRE(K >= 0 && K < (1LL << 31), "gemm_tn_multi: K out of range");
   NK_TRY(ensure_zero_page(ctx));
@@ -389,6 +417,7 @@ int launch_gemm_tn_multi(nk_ctx* ctx, const TnProblem* probs, int nprob, int64_t
     d.A = s.A; d.B = s.B; d.lda = s.lda; d.ldb = s.ldb; d.M = s.M; d.N = s.N;
     d.tiles_n = tnn; d.tri = s.tri; d.ktrim = s.ktrim; d.tile_begin = ntiles;
     d.C = s.C; d.ldc = s.ldc; d.alpha = s.alpha; d.beta = s.beta; d.Ct = s.Ct; d.ldct = s.ldct;
+    d.pass = s.pass; d.ldpass = s.ldpass;
     TnRed& r = R.p[q];
     r.Ct = s.Ct; r.ldct = s.ldct;
     r.C = s.C; r.ldc = s.ldc; r.M = s.M; r.N = s.N; r.tiles_n = tnn; r.tri = s.tri; r.tile_begin = ntiles;
@@ -434,6 +463,8 @@ int launch_gemm_tn_multi(nk_ctx* ctx, const TnProblem* probs, int nprob, int64_t
   if (splitk > 1) NK_TRY(arena_alloc_t(ctx, (size_t)ntiles * splitk * TBM * TBM, &slab));
   P.slab = slab;
   R.nprob = nprob; R.splitk = splitk; R.slab = slab;
+  P.skip_state = R.skip_state = skip ? skip->state : nullptr;
+  P.skip_step = R.skip_step = skip ? skip->step : 0;
   if (!g_tn_attr_set) {
     NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_f64_kernel<0>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES));
@@ -566,10 +597,11 @@ int launch_kmat_gram(nk_ctx* ctx, int ktype, const double* At, int64_t ldat, con
   tp.A = At; tp.B = Bt; tp.lda = ldat; tp.ldb = ldbt; tp.M = (int)nA; tp.N = (int)nB;
   NK_REQUIRE(tn_fast_ok(tp), "kmat_gram: operands violate the alignment contract");
   TnParams P;
+  P.skip_state = nullptr; P.skip_step = 0;
   const int tmn = (int)((nA + TBM - 1) / TBM), tnn = (int)((nB + TBM - 1) / TBM);
   TnDev& dv = P.p[0];
   dv.A = At; dv.B = Bt; dv.lda = ldat; dv.ldb = ldbt; dv.M = (int)nA; dv.N = (int)nB; dv.tiles_n = tnn; dv.tri = TRI_FULL;
-  dv.tile_begin = 0; dv.ktrim = KTRIM_NONE;
+  dv.tile_begin = 0; dv.ktrim = KTRIM_NONE; dv.pass = nullptr; dv.ldpass = 0;
   dv.C = nullptr; dv.ldc = 0; dv.alpha = 1.0; dv.beta = 0.0; dv.Ct = nullptr; dv.ldct = 0;
   for (int q = 1; q < TN_MAXP; ++q) { P.p[q] = P.p[0]; P.p[q].tile_begin = 1 << 30; }
   P.nprob = 1; P.ntiles = tmn * tnn; P.K = d; P.splitk = 1;

@@ -637,6 +637,17 @@ int sqrtm_prepare(nk_ctx* ctx, const double* P, int64_t ldp, int m, SqrtPlan* pl
   CholSys y;
   y.P = plan->W; y.ldp = m; y.m = m; y.extra = m; y.backward = false; y.Linv = plan->Linv;
   NK_TRY(cholesky_aug_pair_async(ctx, &y, 1));  // W <- [L ; L^-T]
+  {
+    // ||L^-1||_F^2 (the extra rows hold L^-T): 1 / it bounds the smallest eigenvalue of P from below
+    const ArenaMark mk = arena_mark(ctx);
+    const int blocks = grid_for((int64_t)m * m, ctx->num_cu);
+    double* partial = nullptr;
+    NK_TRY(arena_alloc_t(ctx, (size_t)2 * blocks, &partial));
+    hipLaunchKernelGGL(sumsq_trace_partial_kernel, dim3(blocks), dim3(256), 0, ctx->stream, E, (int64_t)m, m, partial, blocks);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, ctx->stream, partial, blocks, plan->d_sc + 3);
+    NK_HIP(hipGetLastError());
+    arena_release(ctx, mk);
+  }
   const int tb = (m + 31) / 32;
   hipLaunchKernelGGL(tri_scale_both_kernel, dim3(tb, tb), dim3(256), 0, ctx->stream, plan->W, (int64_t)m, m, plan->d_sc,
                      plan->X0t, plan->X0);
@@ -644,19 +655,55 @@ int sqrtm_prepare(nk_ctx* ctx, const double* P, int64_t ldp, int m, SqrtPlan* pl
   return NK_OK;
 }
 
-int sqrtm_finish(nk_ctx* ctx, SqrtPlan* plan, double* S, double* Sinv, int* iters, double* resid) {
+// convergence bookkeeping of the queued iteration (one thread): state[0] = step + 1 of the first step whose residual is
+// below 1e-7 (0: not yet), state[1] = that residual, state[2] = last residual seen
+__global__ void ns_flag_kernel(const double* __restrict__ r2, int m, int step, double* __restrict__ state) {
+  const double r = sqrt(r2[0] / m);
+  state[2] = r;
+  if (state[0] == 0.0 && r < 1e-7) {
+    state[0] = (double)(step + 1);
+    state[1] = r;
+  }
+}
+
+// S = Q^T L^T = sqrt(c) Q^T X_0 ;  S^-1 = L^-T Q = (L^-1)^T Q with L^-1 = (extra rows)^T   (Q = the converged iterate)
+static int sqrtm_polar_products(nk_ctx* ctx, SqrtPlan* plan, const double* Q, double* scratch, double c, double* S,
+                                double* Sinv) {
+  const int m = plan->m;
+  const size_t mm = (size_t)m * m;
+  double* Linv_full = scratch;
+  NK_TRY(launch_transpose(ctx, plan->W + mm, m, Linv_full, m, m, m));
+  TnProblem pr[2];
+  pr[0].A = Q; pr[0].B = plan->X0; pr[0].C = S; pr[0].lda = pr[0].ldb = pr[0].ldc = m; pr[0].M = pr[0].N = m;
+  pr[0].alpha = std::sqrt(c);
+  pr[0].ktrim = KTRIM_B_UPPER;  // X_0 = L^T / sqrt(c) is upper triangular
+  pr[1].ktrim = KTRIM_A_LOWER;  // L^-1 is lower triangular
+  pr[1].A = Linv_full; pr[1].B = Q; pr[1].C = Sinv; pr[1].lda = pr[1].ldb = pr[1].ldc = m; pr[1].M = pr[1].N = m;
+  if (tn_fast_ok(pr[0]) && tn_fast_ok(pr[1]) && m >= 128) {
+    NK_TRY(launch_gemm_tn_multi(ctx, pr, 2, m, 0));
+  } else {
+    NK_TRY(launch_gemm(ctx, true, false, m, m, m, pr[0].alpha, Q, m, plan->X0, m, 0.0, S, m));
+    NK_TRY(launch_gemm(ctx, true, false, m, m, m, 1.0, Linv_full, m, Q, m, 0.0, Sinv, m));
+  }
+  return NK_OK;
+}
+
+int sqrtm_finish(nk_ctx* ctx, SqrtPlan* plan, double* S, double* Sinv) {
   const int m = plan->m;
   const size_t mm = (size_t)m * m;
   const int ib = info_base(ctx);
-  NK_HIP(hipMemcpyAsync(ctx->h_scalars, plan->d_sc, 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  plan->deferred = false;
+  plan->rc = NK_OK; plan->iters = 0; plan->resid = 0.0;
+  NK_HIP(hipMemcpyAsync(ctx->h_scalars, plan->d_sc, 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   NK_HIP(hipMemcpyAsync(ctx->h_info + ib, ctx->d_info + ib, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-  NK_HIP(hipStreamSynchronize(ctx->stream));
-  const double c = ctx->h_scalars[0], sumsq = ctx->h_scalars[1], trace = ctx->h_scalars[2];
-  if (ctx->h_info[ib] != 0 || !(c > 0.0) || !std::isfinite(c)) {
+  NK_HIP(hipStreamSynchronize(ctx->stream));  // the one host round trip of the square root
+  const double c = ctx->h_scalars[0], sumsq = ctx->h_scalars[1], trace = ctx->h_scalars[2], linv2 = ctx->h_scalars[3];
+  if (ctx->h_info[ib] != 0 || !(c > 0.0) || !std::isfinite(c) || !(linv2 > 0.0) || !std::isfinite(linv2)) {
     // not numerically positive definite for the Cholesky route (e.g. a rank-deficient kernel matrix with a jitter below
     // the rounding level): the coupled iteration needs no factorisation
     arena_release(ctx, plan->mark);
-    return sqrtm_spd_coupled(ctx, plan->P, plan->ldp, m, S, Sinv, iters, resid);
+    plan->rc = sqrtm_spd_coupled(ctx, plan->P, plan->ldp, m, S, Sinv, &plan->iters, &plan->resid);
+    return plan->rc;
   }
   double *Xa = nullptr, *Xta = nullptr, *Xb = nullptr, *Xtb = nullptr, *M = nullptr, *T = nullptr;
   NK_TRY(arena_alloc_t(ctx, mm, &Xa));
@@ -677,11 +724,85 @@ int sqrtm_finish(nk_ctx* ctx, SqrtPlan* plan, double* S, double* Sinv, int* iter
     if (a_lo > 1.0) a_lo = 1.0;
   }
   auto p3 = [](double x) { return x * (3.0 - x) * (3.0 - x) * 0.25; };
+  // one step of the interval recurrence under the scaling s2
+  auto advance = [&](double s2, double& a, double& b) {
+    const double xa = s2 * a, xb = s2 * b;
+    const double lo = p3(xa) < p3(xb) ? p3(xa) : p3(xb);
+    b = (xa <= 1.0 && xb >= 1.0) ? 1.0 : (p3(xa) > p3(xb) ? p3(xa) : p3(xb));
+    a = lo < b ? lo : b;
+  };
   GemmOpts sym;
   sym.tri = TRI_UPPER_MIRROR;
   const double* X = plan->X0;
   const double* Xt = plan->X0t;
   double *Xn = Xa, *Xtn = Xta;
+  TnProblem probe;
+  probe.A = Xta; probe.B = T; probe.C = Xa; probe.lda = probe.ldb = probe.ldc = m; probe.M = probe.N = m;
+  const bool fast = m >= 128 && tn_fast_ok(probe);
+
+  if (fast) {
+    // ---- the whole iteration is queued without host round trips.  The step count is data dependent, so (a) a rigorous
+    // lower bound of the smallest eigenvalue, lambda_min(P) >= 1 / ||L^-1||_F^2, run through the scaling schedule
+    // gives the latest step kmax at which the iteration can converge, and (b) the launches of steps after the one that
+    // actually converged are skipped on the device (TnSkip: the GEMMs exit at once, the X T launch passes the iterate
+    // through), so the converged iterate always ends up in the buffer of step kmax.
+    double s2s[128];
+    bool checks[128];
+    int kmax = 0;
+    {
+      double a = a_lo, b = b_hi;                   // schedule (from the over-estimate, as before)
+      double ta = 0.5 / (c * linv2), tb = 1.0;     // true interval: [lower bound / 2, 1]
+      if (ta > a) ta = a;
+      int kconv = -1;
+      for (int k = 0; k < 100; ++k) {
+        if (kconv < 0 && ta >= 1.0 - 1e-9 && tb <= 1.0 + 1e-9) kconv = k;  // M_k is within the 1e-7 residual bar
+        checks[k] = a >= 0.5;
+        const double s2 = 3.0 / (a + std::sqrt(a * b) + b);
+        s2s[k] = s2;
+        advance(s2, a, b);
+        advance(s2, ta, tb);
+        if (kconv >= 0 && k >= kconv + 1) { kmax = k + 1; break; }  // one spare step beyond the predicted last one
+      }
+      if (kmax == 0) kmax = 100;
+    }
+    double* state = plan->d_sc + 5;
+    NK_HIP(hipMemsetAsync(state, 0, 3 * sizeof(double), ctx->stream));
+    for (int k = 0; k < kmax; ++k) {
+      const TnSkip skip{state, k};
+      if (k == 0) {
+        NK_TRY(launch_transpose(ctx, plan->P, plan->ldp, M, m, m, m));
+        NK_TRY(launch_axpby2d(ctx, 0.5 / c, plan->P, plan->ldp, 0.5 / c, M, m, m, m));
+      } else {
+        TnProblem pm;
+        pm.A = X; pm.B = X; pm.C = M; pm.lda = pm.ldb = pm.ldc = m; pm.M = pm.N = m; pm.tri = TRI_UPPER_MIRROR;
+        NK_TRY(launch_gemm_tn_multi(ctx, &pm, 1, m, 0, nullptr, true, &skip));  // M = X^T X
+      }
+      if (checks[k]) {
+        NK_TRY(launch_frob_minus_identity(ctx, M, m, m, ctx->d_scalars));
+        hipLaunchKernelGGL(ns_flag_kernel, dim3(1), dim3(1), 0, ctx->stream, ctx->d_scalars, m, k, state);
+        NK_HIP(hipGetLastError());
+      }
+      const double s2 = s2s[k], sc = std::sqrt(s2);
+      NK_TRY(launch_scale_add_identity(ctx, -0.5 * s2 * sc, M, m, 1.5 * sc, T, m, m));
+      TnProblem pr;
+      pr.A = Xt; pr.B = T; pr.C = Xn; pr.lda = pr.ldb = pr.ldc = m; pr.M = pr.N = m; pr.Ct = Xtn; pr.ldct = m;
+      pr.pass = X; pr.ldpass = m;
+      // one K slice: at most one workgroup slot per CU is taken, the other stays free for the factorisation chain on the
+      // main stream (a two-slice launch would take every slot for its whole duration)
+      NK_TRY(launch_gemm_tn_multi(ctx, &pr, 1, m, 1, nullptr, true, &skip));
+      X = Xn; Xt = Xtn;
+      Xn = (Xn == Xa) ? Xb : Xa;
+      Xtn = (Xtn == Xta) ? Xtb : Xta;
+    }
+    NK_TRY(sqrtm_polar_products(ctx, plan, X, T, c, S, Sinv));
+    NK_HIP(hipMemcpyAsync(ctx->h_scalars + 8, state, 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    plan->deferred = true;
+    plan->kmax = kmax;
+    arena_release(ctx, plan->mark);
+    return NK_OK;
+  }
+
+  // ---- small / unaligned matrices: generic engine, convergence read by the host (one step behind the queue)
   const int maxit = 100;
   double r = 1e300;
   int it = 0;
@@ -694,10 +815,6 @@ int sqrtm_finish(nk_ctx* ctx, SqrtPlan* plan, double* S, double* Sinv, int* iter
     } else {
       NK_TRY(launch_gemm(ctx, true, false, m, m, m, 1.0, X, m, X, m, 0.0, M, m, sym));  // M = X^T X
     }
-    // Convergence checks (skipped during the growth phase, see the coupled iteration) do not stall the stream: the
-    // residual of M_k is reduced and copied asynchronously, step k is queued behind it, and only then does the host
-    // wait for the number -- the GPU is busy with the product of step k meanwhile.  A residual below 1e-7 means that
-    // X_{k+1} = X_k T_k (already queued) sits on the rounding floor (quadratic convergence), so it is the result.
     const bool check = a_lo >= 0.5 || it + 2 >= maxit;
     if (check) {
       NK_TRY(launch_frob_minus_identity(ctx, M, m, m, ctx->d_scalars));
@@ -706,27 +823,10 @@ int sqrtm_finish(nk_ctx* ctx, SqrtPlan* plan, double* S, double* Sinv, int* iter
     }
     const double s2 = 3.0 / (a_lo + std::sqrt(a_lo * b_hi) + b_hi);
     const double sc = std::sqrt(s2);
-    {
-      const double xa = s2 * a_lo, xb = s2 * b_hi;
-      const double lo = p3(xa) < p3(xb) ? p3(xa) : p3(xb);
-      b_hi = (xa <= 1.0 && xb >= 1.0) ? 1.0 : (p3(xa) > p3(xb) ? p3(xa) : p3(xb));
-      a_lo = lo < b_hi ? lo : b_hi;
-    }
+    advance(s2, a_lo, b_hi);
     NK_TRY(launch_scale_add_identity(ctx, -0.5 * s2 * sc, M, m, 1.5 * sc, T, m, m));
-    {
-      // X T = (X^T)^T T on the TN engine; the epilogue also writes the transpose for the next step
-      TnProblem pr;
-      pr.A = Xt; pr.B = T; pr.C = Xn; pr.lda = pr.ldb = pr.ldc = m; pr.M = pr.N = m; pr.Ct = Xtn; pr.ldct = m;
-      if (tn_fast_ok(pr) && m >= 128) {
-        // one K slice while the tiles fill at most one workgroup slot per CU: the other slot stays free for the
-        // factorisation chain on the main stream (a two-slice launch would take every slot for its whole duration)
-        const int tiles = ((m + 127) / 128) * ((m + 127) / 128);
-        NK_TRY(launch_gemm_tn_multi(ctx, &pr, 1, m, tiles <= ctx->num_cu ? 1 : 0));
-      } else {
-        NK_TRY(launch_gemm(ctx, true, false, m, m, m, 1.0, Xt, m, T, m, 0.0, Xn, m));
-        NK_TRY(launch_transpose(ctx, Xn, m, Xtn, m, m, m));
-      }
-    }
+    NK_TRY(launch_gemm(ctx, true, false, m, m, m, 1.0, Xt, m, T, m, 0.0, Xn, m));
+    NK_TRY(launch_transpose(ctx, Xn, m, Xtn, m, m, m));
     X = Xn; Xt = Xtn;
     Xn = (Xn == Xa) ? Xb : Xa;
     Xtn = (Xtn == Xta) ? Xtb : Xta;
@@ -741,36 +841,45 @@ int sqrtm_finish(nk_ctx* ctx, SqrtPlan* plan, double* S, double* Sinv, int* iter
       }
     }
   }
-  if (iters) *iters = it;
-  if (resid) *resid = r;
+  plan->iters = it;
+  plan->resid = r;
   if (!ok) {
     set_error("sqrtm: Newton-Schulz did not converge (residual %g after %d iterations)", r, it);
     arena_release(ctx, plan->mark);
-    return NK_ERR_NO_CONVERGENCE;
+    plan->rc = NK_ERR_NO_CONVERGENCE;
+    return plan->rc;
   }
-  // S = Q^T L^T = sqrt(c) Q^T X_0 ;  S^-1 = L^-T Q = (L^-1)^T Q with L^-1 = (extra rows)^T
-  double* Linv_full = T;  // T is free now
-  NK_TRY(launch_transpose(ctx, plan->W + mm, m, Linv_full, m, m, m));
-  TnProblem pr[2];
-  pr[0].A = X; pr[0].B = plan->X0; pr[0].C = S; pr[0].lda = pr[0].ldb = pr[0].ldc = m; pr[0].M = pr[0].N = m;
-  pr[0].alpha = std::sqrt(c);
-  pr[0].ktrim = KTRIM_B_UPPER;  // X_0 = L^T / sqrt(c) is upper triangular
-  pr[1].ktrim = KTRIM_A_LOWER;  // L^-1 is lower triangular
-  pr[1].A = Linv_full; pr[1].B = X; pr[1].C = Sinv; pr[1].lda = pr[1].ldb = pr[1].ldc = m; pr[1].M = pr[1].N = m;
-  if (tn_fast_ok(pr[0]) && tn_fast_ok(pr[1]) && m >= 128) {
-    NK_TRY(launch_gemm_tn_multi(ctx, pr, 2, m, 0));
-  } else {
-    NK_TRY(launch_gemm(ctx, true, false, m, m, m, pr[0].alpha, X, m, plan->X0, m, 0.0, S, m));
-    NK_TRY(launch_gemm(ctx, true, false, m, m, m, 1.0, Linv_full, m, X, m, 0.0, Sinv, m));
-  }
+  NK_TRY(sqrtm_polar_products(ctx, plan, X, T, c, S, Sinv));
   arena_release(ctx, plan->mark);
   return NK_OK;
+}
+
+int sqrtm_verdict(nk_ctx* ctx, SqrtPlan* plan, int* iters, double* resid) {
+  if (plan->deferred) {
+    const double flag = ctx->h_scalars[8];
+    plan->deferred = false;
+    if (flag == 0.0 || !std::isfinite(ctx->h_scalars[10])) {
+      plan->iters = plan->kmax;
+      plan->resid = ctx->h_scalars[10];
+      plan->rc = NK_ERR_NO_CONVERGENCE;
+      set_error("sqrtm: Newton-Schulz did not converge (residual %g after %d iterations)", plan->resid, plan->kmax);
+    } else {
+      plan->iters = (int)flag;
+      plan->resid = ctx->h_scalars[9];
+      plan->rc = NK_OK;
+    }
+  }
+  if (iters) *iters = plan->iters;
+  if (resid) *resid = plan->resid;
+  return plan->rc;
 }
 
 int sqrtm_spd(nk_ctx* ctx, const double* P, int64_t ldp, int m, double* S, double* Sinv, int* iters, double* resid) {
   SqrtPlan plan;
   NK_TRY(sqrtm_prepare(ctx, P, ldp, m, &plan));
-  return sqrtm_finish(ctx, &plan, S, Sinv, iters, resid);
+  NK_TRY(sqrtm_finish(ctx, &plan, S, Sinv));
+  NK_HIP(hipStreamSynchronize(ctx->stream));
+  return sqrtm_verdict(ctx, &plan, iters, resid);
 }
 
 }  // namespace nk
