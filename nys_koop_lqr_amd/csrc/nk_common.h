@@ -151,15 +151,17 @@ struct GemmCall {
 // up to two independent problems with the same transposition flags in one launch (no split-K)
 int launch_gemm_pair(nk_ctx* ctx, bool transA, bool transB, const GemmCall* calls, int ncalls);
 
+struct TnSkip;  // device-side launch control, defined with the TN engine below
 // elementwise / reductions
 int launch_add_diag(nk_ctx* ctx, double* A, int64_t lda, int n, double v);
 int launch_copy2d(nk_ctx* ctx, const double* src, int64_t lds, double* dst, int64_t ldd, int64_t rows, int64_t cols);
 int launch_axpby2d(nk_ctx* ctx, double a, const double* X, int64_t ldx, double b, double* Y, int64_t ldy,
                    int64_t rows, int64_t cols);  // Y = a*X + b*Y
 int launch_scale_add_identity(nk_ctx* ctx, double a, const double* X, int64_t ldx, double c, double* Y, int64_t ldy,
-                              int n);  // Y = a*X + c*I
+                              int n, const TnSkip* skip = nullptr);  // Y = a*X + c*I
 int launch_fill(nk_ctx* ctx, double* A, int64_t lda, int64_t rows, int64_t cols, double v);
-int launch_frob_minus_identity(nk_ctx* ctx, const double* M, int64_t ldm, int n, double* d_out);  // sum (M-I)^2
+int launch_frob_minus_identity(nk_ctx* ctx, const double* M, int64_t ldm, int n, double* d_out,
+                               const TnSkip* skip = nullptr);  // sum (M-I)^2
 int launch_max_abs_rowsum(nk_ctx* ctx, const double* M, int64_t ldm, int n, double* d_out);
 int launch_colsum_sqdiff(nk_ctx* ctx, const double* P, int64_t ldp, const double* Y, int64_t ldy, int64_t rows,
                          int cols, double* d_colsum);  // colsum[j] = sum_i (P[i][j]-Y[i][j])^2
@@ -241,15 +243,17 @@ struct TnProblem {
   double alpha = 1.0, beta = 0.0;
   double* Ct = nullptr;  // optional: also store the transpose, Ct[col][row] = C[row][col] (N x M, leading dim ldct)
   int64_t ldct = 0;
-  const double* pass = nullptr;  // conditional launches (TnSkip): matrix copied to C / Ct when the launch is skipped
-  int64_t ldpass = 0;
+  const double* A_even = nullptr;  // operand selection (TnSkip::select): alternatives of A / B for an even step count
+  const double* B_even = nullptr;
 };
-// Device-side condition of a launch: skipped when state[0] != 0 && state[0] <= step (single-slice launches then copy
-// `pass` to the outputs, split-K launches and their reduce just return).  Lets an iteration with a data-dependent length
-// be queued in full without host round trips.
+// Device-side control of a launch, so that an iteration with a data-dependent length can be queued in full without host
+// round trips.  state: the launch returns at once when state[0] != 0 && state[0] <= step (state[0] = number of steps after
+// which the iteration converged, written on the device).  select: the parity of select[0] picks A/B (odd) or
+// A_even/B_even (even) -- the buffer of a ping-pong iteration that holds the final iterate.
 struct TnSkip {
-  const double* state;
-  int step;
+  const double* state = nullptr;
+  int step = 0;
+  const double* select = nullptr;
 };
 bool tn_fast_ok(const TnProblem& p);  // alignment / leading-dimension requirements of the LDS-DMA path
 int launch_gemm_tn_multi(nk_ctx* ctx, const TnProblem* probs, int nprob, int64_t K, int splitk /*0=auto*/,

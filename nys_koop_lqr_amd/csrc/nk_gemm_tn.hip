@@ -40,8 +40,8 @@ struct TnDev {
   double alpha, beta;
   double* Ct;      // optional transposed copy of the result
   int64_t ldct;
-  const double* pass;  // conditional launches: when the launch is skipped, C (and Ct) receive this matrix instead
-  int64_t ldpass;
+  const double* A_even;  // operand selection (TnParams::select_state): used instead of A / B when the step count
+  const double* B_even;  // in select_state[0] is even (nullptr: no alternative)
 };
 struct TnParams {
   TnDev p[TN_MAXP];
@@ -54,6 +54,9 @@ struct TnParams {
   // launch is skipped when skip_state[0] != 0 && skip_state[0] <= skip_step
   const double* skip_state;
   int skip_step;
+  // operand selection: the result of a ping-pong iteration of data-dependent length lives in one of two buffers; the
+  // parity of select_state[0] (the number of steps actually taken, written on the device) picks A/B or A_even/B_even
+  const double* select_state;
   // fused kernel-matrix epilogue (EPI == 1): out[i][j] = k(sqa[i] + sqb[j] - 2 acc)
   const double* sqa;
   const double* sqb;
@@ -108,19 +111,13 @@ __device__ __forceinline__ void tn_body(const TnParams& P) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (EPI == 0 && P.skip_state != nullptr) {
     const double f = P.skip_state[0];
-    if (f != 0.0 && f <= (double)P.skip_step) {
-      if (pr.pass != nullptr && P.splitk == 1) {  // pass the previous iterate through: C = pass (and Ct = pass^T)
-        for (int e = threadIdx.x; e < TBM * TBM; e += 256) {
-          const int row = tm * TBM + (e >> 7), col = tn * TBM + (e & 127);
-          if (row < pr.M && col < pr.N) {
-            const double v = pr.pass[(int64_t)row * pr.ldpass + col];
-            pr.C[(int64_t)row * pr.ldc + col] = v;
-            if (pr.Ct) pr.Ct[(int64_t)col * pr.ldct + row] = v;
-          }
-        }
-      }
-      return;
-    }
+    if (f != 0.0 && f <= (double)P.skip_step) return;
+  }
+  const double* opA = pr.A;
+  const double* opB = pr.B;
+  if (EPI == 0 && P.select_state != nullptr && (((int)P.select_state[0]) & 1) == 0) {
+    if (pr.A_even) opA = pr.A_even;
+    if (pr.B_even) opB = pr.B_even;
   }
   int kbeg = split * P.klen;
   int kend = min(P.K, kbeg + P.klen);
@@ -143,8 +140,8 @@ __device__ __forceinline__ void tn_body(const TnParams& P) {
       const int r = wave + 4 * q;
       const int k = k0 + r;
       const bool ok = k < kend;
-      const double* ga = ok ? pr.A + (int64_t)k * pr.lda + ca : zsrc;
-      const double* gb = ok ? pr.B + (int64_t)k * pr.ldb + cb : zsrc;
+      const double* ga = ok ? opA + (int64_t)k * pr.lda + ca : zsrc;
+      const double* gb = ok ? opB + (int64_t)k * pr.ldb + cb : zsrc;
       dma_row(ga, sa + r * TSTRIDE);
       dma_row(gb, sb + r * TSTRIDE);
     }
@@ -417,7 +414,7 @@ int launch_gemm_tn_multi(nk_ctx* ctx, const TnProblem* probs, int nprob, int64_t
     d.A = s.A; d.B = s.B; d.lda = s.lda; d.ldb = s.ldb; d.M = s.M; d.N = s.N;
     d.tiles_n = tnn; d.tri = s.tri; d.ktrim = s.ktrim; d.tile_begin = ntiles;
     d.C = s.C; d.ldc = s.ldc; d.alpha = s.alpha; d.beta = s.beta; d.Ct = s.Ct; d.ldct = s.ldct;
-    d.pass = s.pass; d.ldpass = s.ldpass;
+    d.A_even = s.A_even; d.B_even = s.B_even;
     TnRed& r = R.p[q];
     r.Ct = s.Ct; r.ldct = s.ldct;
     r.C = s.C; r.ldc = s.ldc; r.M = s.M; r.N = s.N; r.tiles_n = tnn; r.tri = s.tri; r.tile_begin = ntiles;
@@ -465,6 +462,7 @@ int launch_gemm_tn_multi(nk_ctx* ctx, const TnProblem* probs, int nprob, int64_t
   R.nprob = nprob; R.splitk = splitk; R.slab = slab;
   P.skip_state = R.skip_state = skip ? skip->state : nullptr;
   P.skip_step = R.skip_step = skip ? skip->step : 0;
+  P.select_state = skip ? skip->select : nullptr;
   if (!g_tn_attr_set) {
     NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_f64_kernel<0>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES));
@@ -597,11 +595,11 @@ int launch_kmat_gram(nk_ctx* ctx, int ktype, const double* At, int64_t ldat, con
   tp.A = At; tp.B = Bt; tp.lda = ldat; tp.ldb = ldbt; tp.M = (int)nA; tp.N = (int)nB;
   NK_REQUIRE(tn_fast_ok(tp), "kmat_gram: operands violate the alignment contract");
   TnParams P;
-  P.skip_state = nullptr; P.skip_step = 0;
+  P.skip_state = nullptr; P.skip_step = 0; P.select_state = nullptr;
   const int tmn = (int)((nA + TBM - 1) / TBM), tnn = (int)((nB + TBM - 1) / TBM);
   TnDev& dv = P.p[0];
   dv.A = At; dv.B = Bt; dv.lda = ldat; dv.ldb = ldbt; dv.M = (int)nA; dv.N = (int)nB; dv.tiles_n = tnn; dv.tri = TRI_FULL;
-  dv.tile_begin = 0; dv.ktrim = KTRIM_NONE; dv.pass = nullptr; dv.ldpass = 0;
+  dv.tile_begin = 0; dv.ktrim = KTRIM_NONE; dv.A_even = dv.B_even = nullptr;
   dv.C = nullptr; dv.ldc = 0; dv.alpha = 1.0; dv.beta = 0.0; dv.Ct = nullptr; dv.ldct = 0;
   for (int q = 1; q < TN_MAXP; ++q) { P.p[q] = P.p[0]; P.p[q].tile_begin = 1 << 30; }
   P.nprob = 1; P.ntiles = tmn * tnn; P.K = d; P.splitk = 1;

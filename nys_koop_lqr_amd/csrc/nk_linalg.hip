@@ -35,8 +35,15 @@ __global__ void axpby2d_kernel(double a, const double* __restrict__ X, int64_t l
     Y[r * ldy + c] = a * X[r * ldx + c] + y;
   }
 }
+__device__ __forceinline__ bool launch_skipped(const double* state, int step) {
+  if (state == nullptr) return false;
+  const double f = state[0];
+  return f != 0.0 && f <= (double)step;
+}
 __global__ void scale_add_identity_kernel(double a, const double* __restrict__ X, int64_t ldx, double c,
-                                          double* __restrict__ Y, int64_t ldy, int n) {
+                                          double* __restrict__ Y, int64_t ldy, int n, const double* skip_state,
+                                          int skip_step) {
+  if (launch_skipped(skip_state, skip_step)) return;
   const int64_t total = (int64_t)n * n;
   for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
     const int64_t r = e / n, col = e - r * n;
@@ -64,7 +71,9 @@ __device__ __forceinline__ double wave_max(double v) {
 
 // per-block partial sums of (M - I)^2; finished by a second single-block pass (deterministic order)
 __global__ void __launch_bounds__(256) frob_mi_partial_kernel(const double* __restrict__ M, int64_t ldm, int n,
-                                                              double* __restrict__ partial) {
+                                                              double* __restrict__ partial, const double* skip_state,
+                                                              int skip_step) {
+  if (launch_skipped(skip_state, skip_step)) return;  // the stale partials give the old residual: harmless
   __shared__ double sh[4];
   const int64_t total = (int64_t)n * n;
   double s = 0.0;
@@ -188,10 +197,10 @@ int launch_axpby2d(nk_ctx* ctx, double a, const double* X, int64_t ldx, double b
   return NK_OK;
 }
 int launch_scale_add_identity(nk_ctx* ctx, double a, const double* X, int64_t ldx, double c, double* Y, int64_t ldy,
-                              int n) {
+                              int n, const TnSkip* skip) {
   if (n <= 0) return NK_OK;
   hipLaunchKernelGGL(scale_add_identity_kernel, dim3(grid_for((int64_t)n * n, ctx->num_cu)), dim3(256), 0, ctx->stream,
-                     a, X, ldx, c, Y, ldy, n);
+                     a, X, ldx, c, Y, ldy, n, skip ? skip->state : nullptr, skip ? skip->step : 0);
   NK_HIP(hipGetLastError());
   return NK_OK;
 }
@@ -202,12 +211,13 @@ int launch_fill(nk_ctx* ctx, double* A, int64_t lda, int64_t rows, int64_t cols,
   NK_HIP(hipGetLastError());
   return NK_OK;
 }
-int launch_frob_minus_identity(nk_ctx* ctx, const double* M, int64_t ldm, int n, double* d_out) {
+int launch_frob_minus_identity(nk_ctx* ctx, const double* M, int64_t ldm, int n, double* d_out, const TnSkip* skip) {
   const ArenaMark mk = arena_mark(ctx);
   const int blocks = grid_for((int64_t)n * n, ctx->num_cu);
   double* partial = nullptr;
   NK_TRY(arena_alloc_t(ctx, (size_t)blocks, &partial));
-  hipLaunchKernelGGL(frob_mi_partial_kernel, dim3(blocks), dim3(256), 0, ctx->stream, M, ldm, n, partial);
+  hipLaunchKernelGGL(frob_mi_partial_kernel, dim3(blocks), dim3(256), 0, ctx->stream, M, ldm, n, partial,
+                     skip ? skip->state : nullptr, skip ? skip->step : 0);
   hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, ctx->stream, partial, blocks, d_out);
   NK_HIP(hipGetLastError());
   arena_release(ctx, mk);
@@ -667,8 +677,9 @@ __global__ void ns_flag_kernel(const double* __restrict__ r2, int m, int step, d
 }
 
 // S = Q^T L^T = sqrt(c) Q^T X_0 ;  S^-1 = L^-T Q = (L^-1)^T Q with L^-1 = (extra rows)^T   (Q = the converged iterate)
+// Q_even / select: the iterate after an even number of steps and the device word holding the step count (queued form)
 static int sqrtm_polar_products(nk_ctx* ctx, SqrtPlan* plan, const double* Q, double* scratch, double c, double* S,
-                                double* Sinv) {
+                                double* Sinv, const double* Q_even = nullptr, const double* select = nullptr) {
   const int m = plan->m;
   const size_t mm = (size_t)m * m;
   double* Linv_full = scratch;
@@ -679,8 +690,12 @@ static int sqrtm_polar_products(nk_ctx* ctx, SqrtPlan* plan, const double* Q, do
   pr[0].ktrim = KTRIM_B_UPPER;  // X_0 = L^T / sqrt(c) is upper triangular
   pr[1].ktrim = KTRIM_A_LOWER;  // L^-1 is lower triangular
   pr[1].A = Linv_full; pr[1].B = Q; pr[1].C = Sinv; pr[1].lda = pr[1].ldb = pr[1].ldc = m; pr[1].M = pr[1].N = m;
+  pr[0].A_even = Q_even;
+  pr[1].B_even = Q_even;
+  TnSkip sel;
+  sel.select = select;
   if (tn_fast_ok(pr[0]) && tn_fast_ok(pr[1]) && m >= 128) {
-    NK_TRY(launch_gemm_tn_multi(ctx, pr, 2, m, 0));
+    NK_TRY(launch_gemm_tn_multi(ctx, pr, 2, m, 0, nullptr, true, select ? &sel : nullptr));
   } else {
     NK_TRY(launch_gemm(ctx, true, false, m, m, m, pr[0].alpha, Q, m, plan->X0, m, 0.0, S, m));
     NK_TRY(launch_gemm(ctx, true, false, m, m, m, 1.0, Linv_full, m, Q, m, 0.0, Sinv, m));
@@ -744,8 +759,8 @@ int sqrtm_finish(nk_ctx* ctx, SqrtPlan* plan, double* S, double* Sinv) {
     // ---- the whole iteration is queued without host round trips.  The step count is data dependent, so (a) a rigorous
     // lower bound of the smallest eigenvalue, lambda_min(P) >= 1 / ||L^-1||_F^2, run through the scaling schedule
     // gives the latest step kmax at which the iteration can converge, and (b) the launches of steps after the one that
-    // actually converged are skipped on the device (TnSkip: the GEMMs exit at once, the X T launch passes the iterate
-    // through), so the converged iterate always ends up in the buffer of step kmax.
+    // actually converged return at once on the device (TnSkip), and the two final products pick the buffer that holds
+    // the converged iterate by the parity of the step count (also on the device).
     double s2s[128];
     bool checks[128];
     int kmax = 0;
@@ -768,7 +783,8 @@ int sqrtm_finish(nk_ctx* ctx, SqrtPlan* plan, double* S, double* Sinv) {
     double* state = plan->d_sc + 5;
     NK_HIP(hipMemsetAsync(state, 0, 3 * sizeof(double), ctx->stream));
     for (int k = 0; k < kmax; ++k) {
-      const TnSkip skip{state, k};
+      TnSkip skip;
+      skip.state = state; skip.step = k;
       if (k == 0) {
         NK_TRY(launch_transpose(ctx, plan->P, plan->ldp, M, m, m, m));
         NK_TRY(launch_axpby2d(ctx, 0.5 / c, plan->P, plan->ldp, 0.5 / c, M, m, m, m));
@@ -778,15 +794,14 @@ int sqrtm_finish(nk_ctx* ctx, SqrtPlan* plan, double* S, double* Sinv) {
         NK_TRY(launch_gemm_tn_multi(ctx, &pm, 1, m, 0, nullptr, true, &skip));  // M = X^T X
       }
       if (checks[k]) {
-        NK_TRY(launch_frob_minus_identity(ctx, M, m, m, ctx->d_scalars));
+        NK_TRY(launch_frob_minus_identity(ctx, M, m, m, ctx->d_scalars, &skip));
         hipLaunchKernelGGL(ns_flag_kernel, dim3(1), dim3(1), 0, ctx->stream, ctx->d_scalars, m, k, state);
         NK_HIP(hipGetLastError());
       }
       const double s2 = s2s[k], sc = std::sqrt(s2);
-      NK_TRY(launch_scale_add_identity(ctx, -0.5 * s2 * sc, M, m, 1.5 * sc, T, m, m));
+      NK_TRY(launch_scale_add_identity(ctx, -0.5 * s2 * sc, M, m, 1.5 * sc, T, m, m, &skip));
       TnProblem pr;
       pr.A = Xt; pr.B = T; pr.C = Xn; pr.lda = pr.ldb = pr.ldc = m; pr.M = pr.N = m; pr.Ct = Xtn; pr.ldct = m;
-      pr.pass = X; pr.ldpass = m;
       // one K slice: at most one workgroup slot per CU is taken, the other stays free for the factorisation chain on the
       // main stream (a two-slice launch would take every slot for its whole duration)
       NK_TRY(launch_gemm_tn_multi(ctx, &pr, 1, m, 1, nullptr, true, &skip));
@@ -794,7 +809,8 @@ int sqrtm_finish(nk_ctx* ctx, SqrtPlan* plan, double* S, double* Sinv) {
       Xn = (Xn == Xa) ? Xb : Xa;
       Xtn = (Xtn == Xta) ? Xtb : Xta;
     }
-    NK_TRY(sqrtm_polar_products(ctx, plan, X, T, c, S, Sinv));
+    // X_j lives in Xa for odd j and in Xb for even j; the step count state[0] = j picks the operand on the device
+    NK_TRY(sqrtm_polar_products(ctx, plan, Xa, T, c, S, Sinv, Xb, state));
     NK_HIP(hipMemcpyAsync(ctx->h_scalars + 8, state, 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     plan->deferred = true;
     plan->kmax = kmax;
