@@ -797,8 +797,9 @@ static int fit_impl(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int6
   }
   NK_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
   NK_HIP(hipEventRecord(ev[4], ctx->stream));
-  tr.mark("sqrt done (host-synced, side stream)");
-  NK_TRY(cholesky_check_pair(ctx, sys, 2));
+  tr.mark("side stream joined (queued)");
+  // (the verdict of the factorisations is read at the end of the call: a blocking check here would leave the GPU idle
+  // while the host wakes up and queues the products; on a failed factorisation they compute on garbage, harmlessly)
 
   // ---- operator products; every product is P^T Q with P stored contraction-major (fast TN engine) -----------------------
   //   [A B] = S^-1 (cross inner^-1) blkdiag(K_xo S^-1, I)   with  cross inner^-1 = [V1^T | V2^T] in G2
@@ -814,7 +815,7 @@ static int fit_impl(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int6
   NK_TRY(launch_gemm(ctx, true, false, d, mp, m, 1.0, Ct, ldd, mdl->A, mp, 0.0, mdl->W, mp));  // W = C G (:167)
   NK_HIP(hipEventRecord(ev[5], ctx->stream));
   tr.mark("solve issued");
-  NK_HIP(hipStreamSynchronize(ctx->stream));
+  NK_TRY(cholesky_check_pair(ctx, sys, 2));  // synchronises the main stream (which has joined the side stream)
   tr.mark("final sync");
   NK_TRY(sqrtm_verdict(ctx, &splan, &it, &resid));  // the iteration was queued without host round trips
   mdl->has_ops = true;
