@@ -14,7 +14,7 @@
  *   - Return value: NK_OK (0) or a negative NK_ERR_* code; nk_last_error() gives a thread-local message.
  *     No exceptions or aborts cross the ABI.
  *   - One nk_ctx per (thread, device).  Calls on distinct contexts are re-entrant; a context is not
- *     thread-safe.  A context owns one HIP stream and a grow-only HBM workspace.
+ *     thread-safe.  A context owns its HIP streams (nk_stream() returns the main one) and a grow-only HBM workspace.
  *   - There is NO CPU fallback: without a usable HIP device nk_create fails with NK_ERR_NO_DEVICE.
  */
 #ifndef NYSKOOP_H

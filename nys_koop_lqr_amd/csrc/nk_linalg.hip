@@ -1,9 +1,10 @@
 // Dense symmetric-positive-definite machinery of the O(m^3) stage, built on the fp64 MFMA GEMM engine:
-//   * matrix square root / inverse square root by the coupled Newton-Schulz iteration (GEMM only),
+//   * matrix square root / inverse square root through the polar factor of the Cholesky factor (scaled Newton-Schulz,
+//     GEMM only; the coupled Newton-Schulz iteration is kept as the fallback for numerically singular input),
 //     replacing scipy.linalg.sqrtm + solve(assume_a='her') (regressors.py:140,152,153,163,175,177);
-//   * blocked Cholesky + blocked triangular solves replacing scipy.linalg.lstsq on the (numerically full-rank)
-//     regularised normal matrices (regressors.py:155,165).  A non-positive pivot is reported as NK_ERR_NOT_SPD;
-//     there is no silent rank truncation.
+//   * blocked Cholesky with the right-hand sides riding along as extra rows + a single-launch backward substitution
+//     (nk_trsm.hip), replacing scipy.linalg.lstsq on the (numerically full-rank) regularised normal matrices
+//     (regressors.py:155,165).  A non-positive pivot is reported as NK_ERR_NOT_SPD; there is no silent rank truncation.
 #include "nk_common.h"
 
 #include <algorithm>
