@@ -588,3 +588,21 @@ def test_sample_sharded_fit_two_ranks_one_gpu(nk, O, golden, tmp_path):
     for k, ref in (("A", reg.A), ("B", reg.B), ("C", reg.C), ("W", reg.weights)):
         assert np.array_equal(f0[k], f1[k]), k      # both ranks solve from the same summed accumulator
         assert relf(f0[k], ref) < 1e-9, k
+
+
+@pytest.mark.gpu
+def test_indefinite_system_is_reported_not_computed(nk, O, golden):
+    """A negative ridge makes the regularised normal matrix indefinite: the blocked Cholesky flags the pivot, the queued
+    substitutions / products run on garbage harmlessly, and the call returns NK_ERR_NOT_SPD (LinAlgError) at its end;
+    the context stays usable."""
+    g = golden("f2_synth_rbf_d384.npz")
+    X, Y = g["X"].astype(np.float64), g["Y"].astype(np.float64)
+    d = Y.shape[1]
+    kern, _ = _kernels(nk, O, "rbf", g["ls"], d)
+    bad = nk.KoopmanNystromRegressor(6, kernel=kern, gamma=-10.0, m=len(g["idx"]))
+    bad.nystrom_centers_output = Y.T[:, g["idx"]]
+    with pytest.raises(np.linalg.LinAlgError):
+        bad.fit(X, Y)
+    assert bad._model is None
+    reg, X, Y, d = _fit(nk, O, "rbf", g, 6)  # same context, next call
+    assert relf(reg.A, g["A"]) < 1e-6
