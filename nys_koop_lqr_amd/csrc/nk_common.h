@@ -245,6 +245,8 @@ struct TnProblem {
   int64_t ldct = 0;
   const double* A_even = nullptr;  // operand selection (TnSkip::select): alternatives of A / B for an even step count
   const double* B_even = nullptr;
+  double* Caff = nullptr;  // optional second output Caff = aff_a * C + aff_c * I (same leading dimension as C)
+  double aff_a = 0.0, aff_c = 0.0;
 };
 // Device-side control of a launch, so that an iteration with a data-dependent length can be queued in full without host
 // round trips.  state: the launch returns at once when state[0] != 0 && state[0] <= step (state[0] = number of steps after

@@ -42,6 +42,8 @@ struct TnDev {
   int64_t ldct;
   const double* A_even;  // operand selection (TnParams::select_state): used instead of A / B when the step count
   const double* B_even;  // in select_state[0] is even (nullptr: no alternative)
+  double* Caff;          // optional second output: Caff = aff_a * C + aff_c * I (leading dimension ldc)
+  double aff_a, aff_c;
 };
 struct TnParams {
   TnDev p[TN_MAXP];
@@ -199,6 +201,10 @@ __device__ __forceinline__ void tn_body(const TnParams& P) {
             pr.C[(int64_t)row * pr.ldc + col] = v;
             if (mirror) pr.C[(int64_t)col * pr.ldc + row] = v;
             if (pr.Ct) pr.Ct[(int64_t)col * pr.ldct + row] = v;
+            if (pr.Caff) {
+              pr.Caff[(int64_t)row * pr.ldc + col] = pr.aff_a * v + (row == col ? pr.aff_c : 0.0);
+              if (mirror) pr.Caff[(int64_t)col * pr.ldc + row] = pr.aff_a * v;
+            }
           }
         }
   } else if (EPI == 0) {
@@ -266,6 +272,8 @@ __global__ void __launch_bounds__(256, 2) gram_fused_f64_kernel(TnParams P) {
 struct TnRed {
   double* C;
   double* Ct;
+  double* Caff;  // see TnDev
+  double aff_a, aff_c;
   int64_t ldc, ldct;
   int M, N, tiles_n, tri, tile_begin;
   double alpha, beta;
@@ -336,6 +344,7 @@ __global__ void __launch_bounds__(256) gemm_tn_reduce_kernel(TnRedParams P) {
         v = pr.alpha * s[i][h];
         if (pr.beta != 0.0) v += pr.beta * pr.C[(int64_t)row * pr.ldc + col];
         pr.C[(int64_t)row * pr.ldc + col] = v;
+        if (pr.Caff) pr.Caff[(int64_t)row * pr.ldc + col] = pr.aff_a * v + (row == col ? pr.aff_c : 0.0);
       }
       if (transposed) sh[r][c + h] = v;
     }
@@ -353,6 +362,7 @@ __global__ void __launch_bounds__(256) gemm_tn_reduce_kernel(TnRedParams P) {
     const double v = sh[rb + q][c];
     if (mirror) pr.C[(int64_t)col * pr.ldc + row] = v;
     if (pr.Ct) pr.Ct[(int64_t)col * pr.ldct + row] = v;
+    if (mirror && pr.Caff) pr.Caff[(int64_t)col * pr.ldc + row] = pr.aff_a * v;  // off-diagonal tile: no identity term
   }
 }
 
@@ -415,7 +425,9 @@ int launch_gemm_tn_multi(nk_ctx* ctx, const TnProblem* probs, int nprob, int64_t
     d.tiles_n = tnn; d.tri = s.tri; d.ktrim = s.ktrim; d.tile_begin = ntiles;
     d.C = s.C; d.ldc = s.ldc; d.alpha = s.alpha; d.beta = s.beta; d.Ct = s.Ct; d.ldct = s.ldct;
     d.A_even = s.A_even; d.B_even = s.B_even;
+    d.Caff = s.Caff; d.aff_a = s.aff_a; d.aff_c = s.aff_c;
     TnRed& r = R.p[q];
+    r.Caff = s.Caff; r.aff_a = s.aff_a; r.aff_c = s.aff_c;
     r.Ct = s.Ct; r.ldct = s.ldct;
     r.C = s.C; r.ldc = s.ldc; r.M = s.M; r.N = s.N; r.tiles_n = tnn; r.tri = s.tri; r.tile_begin = ntiles;
     r.alpha = s.alpha; r.beta = s.beta;
@@ -599,7 +611,7 @@ int launch_kmat_gram(nk_ctx* ctx, int ktype, const double* At, int64_t ldat, con
   const int tmn = (int)((nA + TBM - 1) / TBM), tnn = (int)((nB + TBM - 1) / TBM);
   TnDev& dv = P.p[0];
   dv.A = At; dv.B = Bt; dv.lda = ldat; dv.ldb = ldbt; dv.M = (int)nA; dv.N = (int)nB; dv.tiles_n = tnn; dv.tri = TRI_FULL;
-  dv.tile_begin = 0; dv.ktrim = KTRIM_NONE; dv.A_even = dv.B_even = nullptr;
+  dv.tile_begin = 0; dv.ktrim = KTRIM_NONE; dv.A_even = dv.B_even = nullptr; dv.Caff = nullptr; dv.aff_a = dv.aff_c = 0.0;
   dv.C = nullptr; dv.ldc = 0; dv.alpha = 1.0; dv.beta = 0.0; dv.Ct = nullptr; dv.ldct = 0;
   for (int q = 1; q < TN_MAXP; ++q) { P.p[q] = P.p[0]; P.p[q].tile_begin = 1 << 30; }
   P.nprob = 1; P.ntiles = tmn * tnn; P.K = d; P.splitk = 1;

@@ -790,17 +790,22 @@ int sqrtm_finish(nk_ctx* ctx, SqrtPlan* plan, double* S, double* Sinv) {
         NK_TRY(launch_transpose(ctx, plan->P, plan->ldp, M, m, m, m));
         NK_TRY(launch_axpby2d(ctx, 0.5 / c, plan->P, plan->ldp, 0.5 / c, M, m, m, m));
       } else {
+        // M = X^T X and, from the same epilogue, T = s (3 I - s^2 M) / 2 (its coefficients come from the schedule)
+        const double s2k = s2s[k], sck = std::sqrt(s2k);
         TnProblem pm;
         pm.A = X; pm.B = X; pm.C = M; pm.lda = pm.ldb = pm.ldc = m; pm.M = pm.N = m; pm.tri = TRI_UPPER_MIRROR;
-        NK_TRY(launch_gemm_tn_multi(ctx, &pm, 1, m, 0, nullptr, true, &skip));  // M = X^T X
+        pm.Caff = T; pm.aff_a = -0.5 * s2k * sck; pm.aff_c = 1.5 * sck;
+        NK_TRY(launch_gemm_tn_multi(ctx, &pm, 1, m, 0, nullptr, true, &skip));
       }
       if (checks[k]) {
         NK_TRY(launch_frob_minus_identity(ctx, M, m, m, ctx->d_scalars, &skip));
         hipLaunchKernelGGL(ns_flag_kernel, dim3(1), dim3(1), 0, ctx->stream, ctx->d_scalars, m, k, state);
         NK_HIP(hipGetLastError());
       }
-      const double s2 = s2s[k], sc = std::sqrt(s2);
-      NK_TRY(launch_scale_add_identity(ctx, -0.5 * s2 * sc, M, m, 1.5 * sc, T, m, m, &skip));
+      if (k == 0) {
+        const double s2 = s2s[0], sc = std::sqrt(s2);
+        NK_TRY(launch_scale_add_identity(ctx, -0.5 * s2 * sc, M, m, 1.5 * sc, T, m, m, &skip));
+      }
       TnProblem pr;
       pr.A = Xt; pr.B = T; pr.C = Xn; pr.lda = pr.ldb = pr.ldc = m; pr.M = pr.N = m; pr.Ct = Xtn; pr.ldct = m;
       // one K slice: at most one workgroup slot per CU is taken, the other stays free for the factorisation chain on the
