@@ -448,7 +448,11 @@ int cholesky_lower_pair_async(nk_ctx* ctx, const CholSys* sys, int nsys) {
     }
     NK_TRY(launch_potrf_diag_pair(ctx, Ajj, lda, nbj, Li, nsys, jb));
     NK_TRY(launch_gemm_pair(ctx, false, true, panel, nsys));
-    NK_TRY(launch_gemm_pair(ctx, false, true, trail, nsys));
+    {
+      int rc_trail = NK_OK;  // K = 64 rank update: specialised kernel (nk_trail.hip), generic engine otherwise
+      if (!launch_chol_trail_pair(ctx, trail, nsys, &rc_trail)) NK_TRY(launch_gemm_pair(ctx, false, true, trail, nsys));
+      NK_TRY(rc_trail);
+    }
   }
   return NK_OK;
 }
@@ -514,7 +518,11 @@ int cholesky_aug_pair_async(nk_ctx* ctx, const CholSys* sys, int nsys) {
     }
     NK_TRY(launch_potrf_diag_pair(ctx, Ajj, lda, nbj, Li, nsys, jb));
     NK_TRY(launch_gemm_pair(ctx, false, true, panel, nsys));
-    NK_TRY(launch_gemm_pair(ctx, false, true, trail, nsys));
+    {
+      int rc_trail = NK_OK;  // K = 64 rank update: specialised kernel (nk_trail.hip), generic engine otherwise
+      if (!launch_chol_trail_pair(ctx, trail, nsys, &rc_trail)) NK_TRY(launch_gemm_pair(ctx, false, true, trail, nsys));
+      NK_TRY(rc_trail);
+    }
   }
   // backward on the extra rows E (extra x m, now holding (L^-1 R)^T):  E <- E L^-1, one launch (nk_trsm.hip)
   NK_TRY(launch_trsm_right_lower_pair(ctx, sys, nsys));

@@ -1,0 +1,127 @@
+// Trailing update of one step of the blocked Cholesky (nk_linalg.hip: cholesky_aug_pair_async):
+//     C[tm, tn] -= P[tm] P[tn]^T      P = the 64-column panel of this step (rows x 64, row-major, k contiguous),
+// lower tiles of the square part plus full tiles for the extra (right-hand-side) rows, for up to two systems in one
+// launch.  The generic engine (nk_gemm.hip) walks K in register-staged, barrier-separated steps of 16 -- with K = 64 it
+// never reaches a steady state (50 us per launch alone, ~90 us beside the square-root GEMMs, 32 launches on the critical
+// path of a fit).  Here a workgroup takes both 128 x 64 panel blocks of its tile straight from global memory into
+// registers in two halves of K (each lane owns 8 contiguous doubles of its rows: the contraction index is dealt to the
+// lane groups, any assignment works as long as both operands use the same one), multiplies on the matrix pipe
+// (4 waves x 4 x 4 tiles of v_mfma_f64_16x16x4) and read-modify-writes the 128 x 128 tile of C.  No LDS, no barriers.
+#include "nk_common.h"
+
+namespace nk {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+struct TrailSys {
+  const double* P;  // panel: rows x 64
+  int64_t ldp;
+  double* C;        // trailing matrix: rows x rem (lower tiles of the leading rem x rem part + all tiles below it)
+  int64_t ldc;
+  int rows, rem;
+  int tiles_n;      // ceil(rem / 128)
+  int nblocks;
+};
+struct TrailBatch {
+  TrailSys s[2];
+};
+
+__global__ void __launch_bounds__(256) chol_trail_kernel(TrailBatch tb) {
+  const TrailSys s = tb.s[blockIdx.y];
+  if ((int)blockIdx.x >= s.nblocks) return;
+  __builtin_amdgcn_s_setprio(2);  // latency-bound chain beside the GEMM-bound side stream
+  // tile (tm, tn): tile row r of the lower set holds min(r + 1, tiles_n) tiles (rows past the square part are full)
+  int tm = 0, tn = 0;
+  {
+    int rem = blockIdx.x;
+    for (;;) {
+      const int cnt = tm + 1 < s.tiles_n ? tm + 1 : s.tiles_n;
+      if (rem < cnt) break;
+      rem -= cnt;
+      ++tm;
+    }
+    tn = rem;
+  }
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int m0 = tm * 128 + wm * 64, n0 = tn * 128 + wn * 64;
+
+  d4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
+
+  // operand rows of this lane (clamped: rows past the end only feed accumulator entries that are never stored)
+  const double* pa[4];
+  const double* pb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    pa[i] = s.P + (int64_t)min(m0 + 16 * i + l15, s.rows - 1) * s.ldp + 8 * l4;
+    pb[i] = s.P + (int64_t)min(n0 + 16 * i + l15, s.rem - 1) * s.ldp + 8 * l4;  // column c of C <-> panel row c
+  }
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {  // k in [32 h, 32 h + 32): lane group l4 owns k = 32 h + 8 l4 .. + 7
+    double a[4][8], b[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        a[i][ks] = pa[i][32 * h + ks];
+        b[i][ks] = pb[i][32 * h + ks];
+      }
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i][ks], b[j][ks], acc[i][j], 0, 0, 0);
+  }
+  // C -= acc: lane holds rows (l4 + 4 reg) of column l15 of each 16 x 16 tile
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int row = m0 + 16 * i + l4 + 4 * reg;
+        const int col = n0 + 16 * j + l15;
+        if (row < s.rows && col < s.rem) {
+          double* c = s.C + (int64_t)row * s.ldc + col;
+          *c -= acc[i][j][reg];
+        }
+      }
+}
+
+// trailing updates of up to two systems; calls[q] as prepared for the generic engine (A = B = panel, K = 64, alpha = -1,
+// beta = 1, TRI_LOWER).  Returns false when a call does not have that shape (the caller then uses the generic engine).
+bool launch_chol_trail_pair(nk_ctx* ctx, const GemmCall* calls, int ncalls, int* rc) {
+  *rc = NK_OK;
+  TrailBatch tb;
+  int maxblocks = 0;
+  for (int q = 0; q < 2; ++q) {
+    TrailSys& t = tb.s[q];
+    t = TrailSys{};
+    if (q >= ncalls || calls[q].M <= 0 || calls[q].N <= 0) continue;
+    const GemmCall& c = calls[q];
+    if (c.K != 64 || c.A != c.B || c.lda != c.ldb || c.alpha != -1.0 || c.beta != 1.0 || c.opts.tri != TRI_LOWER ||
+        c.M < c.N)
+      return false;
+    t.P = c.A; t.ldp = c.lda; t.C = c.C; t.ldc = c.ldc; t.rows = (int)c.M; t.rem = (int)c.N;
+    t.tiles_n = (t.rem + 127) / 128;
+    const int tiles_m = (t.rows + 127) / 128;
+    t.nblocks = t.tiles_n * (t.tiles_n + 1) / 2 + (tiles_m - t.tiles_n) * t.tiles_n;
+    if (t.nblocks > maxblocks) maxblocks = t.nblocks;
+  }
+  if (maxblocks == 0) return true;
+  hipLaunchKernelGGL(chol_trail_kernel, dim3((unsigned)maxblocks, 2), dim3(256), 0, ctx->stream, tb);
+  if (hipGetLastError() != hipSuccess) {
+    set_error("chol_trail launch failed");
+    *rc = NK_ERR_HIP;
+  }
+  return true;
+}
+
+}  // namespace nk
