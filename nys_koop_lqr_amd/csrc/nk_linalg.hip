@@ -763,8 +763,12 @@ int sqrtm_finish(nk_ctx* ctx, SqrtPlan* plan, double* S, double* Sinv) {
   TnProblem probe;
   probe.A = Xta; probe.B = T; probe.C = Xa; probe.lda = probe.ldb = probe.ldc = m; probe.M = probe.N = m;
   const bool fast = m >= 128 && tn_fast_ok(probe);
+  // Queue the whole iteration (no host round trips) for large matrices; small ones are launch bound, and the spare steps
+  // the rigorous step budget adds (about five at m = 500, six launches each) would cost more than the few
+  // synchronisations of the host-checked loop below.
+  const bool queued = fast && m >= 1024;
 
-  if (fast) {
+  if (queued) {
     // ---- the whole iteration is queued without host round trips.  The step count is data dependent, so (a) a rigorous
     // lower bound of the smallest eigenvalue, lambda_min(P) >= 1 / ||L^-1||_F^2, run through the scaling schedule
     // gives the latest step kmax at which the iteration can converge, and (b) the launches of steps after the one that
@@ -832,7 +836,7 @@ int sqrtm_finish(nk_ctx* ctx, SqrtPlan* plan, double* S, double* Sinv) {
     return NK_OK;
   }
 
-  // ---- small / unaligned matrices: generic engine, convergence read by the host (one step behind the queue)
+  // ---- small / unaligned matrices: convergence read by the host (one step behind the queue)
   const int maxit = 100;
   double r = 1e300;
   int it = 0;
@@ -855,8 +859,14 @@ int sqrtm_finish(nk_ctx* ctx, SqrtPlan* plan, double* S, double* Sinv) {
     const double sc = std::sqrt(s2);
     advance(s2, a_lo, b_hi);
     NK_TRY(launch_scale_add_identity(ctx, -0.5 * s2 * sc, M, m, 1.5 * sc, T, m, m));
-    NK_TRY(launch_gemm(ctx, true, false, m, m, m, 1.0, Xt, m, T, m, 0.0, Xn, m));
-    NK_TRY(launch_transpose(ctx, Xn, m, Xtn, m, m, m));
+    if (fast) {  // X T with the transposed copy from the epilogue
+      TnProblem pr;
+      pr.A = Xt; pr.B = T; pr.C = Xn; pr.lda = pr.ldb = pr.ldc = m; pr.M = pr.N = m; pr.Ct = Xtn; pr.ldct = m;
+      NK_TRY(launch_gemm_tn_multi(ctx, &pr, 1, m, 0));
+    } else {
+      NK_TRY(launch_gemm(ctx, true, false, m, m, m, 1.0, Xt, m, T, m, 0.0, Xn, m));
+      NK_TRY(launch_transpose(ctx, Xn, m, Xtn, m, m, m));
+    }
     X = Xn; Xt = Xtn;
     Xn = (Xn == Xa) ? Xb : Xa;
     Xtn = (Xtn == Xta) ? Xtb : Xta;
