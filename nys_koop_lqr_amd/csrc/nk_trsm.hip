@@ -4,13 +4,13 @@
 // regressors.py:155,165 is X^T = E L^-1, i.e. every ROW x of the result solves x L = e on its own.  The blocked
 // right-looking form (per 64-column block: one small product with the inverted diagonal block, one rank-64 update of the
 // columns to the left) needs 2 launches per block -- 64 dependent, latency-bound launches at m = 2000.  Because the rows
-// are independent, one workgroup can instead carry a band of 32 rows through the whole substitution alone, in the
+// are independent, one workgroup can instead carry a band of 16 rows through the whole substitution alone, in the
 // left-looking order
 //     for j = last block .. 0:   X_j = (E_j - sum_{i > j} X_i L[i, j]) L_jj^-1
 // with the accumulation on the matrix pipe (v_mfma_f64_16x16x4): the band blocks X_i go through LDS (one coalesced
 // cooperative load serves the four waves), the blocks of the factor straight into registers (the factor is read by
 // every band from L2; 16 MB at m = 2000), the next block pair is fetched while the current one is multiplied, and
-// nothing but the finished X_j is written.  63 + 12 workgroups at the C4 shape.
+// nothing but the finished X_j is written.  125 + 24 workgroups at the C4 shape.
 #include "nk_common.h"
 
 namespace nk {
@@ -32,7 +32,9 @@ struct TrsmBatch {
   int nsys;
 };
 
-constexpr int TR_ROWS = 32;  // rows per workgroup: two 16-row MFMA tiles per wave, wave w owns columns 16w..16w+15
+constexpr int TR_RT = 1;              // 16-row MFMA tiles per wave
+constexpr int TR_ROWS = 16 * TR_RT;  // rows per workgroup; wave w owns columns 16w..16w+15 of the current block
+constexpr int TR_PA = TR_ROWS / 4;    // doubles per thread of a cooperative band-block load (256 threads, 64 columns)
 constexpr int TLD = 65;      // odd row stride: the 16 rows an operand fetch touches fall into distinct LDS banks
 
 __global__ void __launch_bounds__(256) trsm_right_lower_kernel(TrsmBatch tb) {
@@ -52,9 +54,10 @@ __global__ void __launch_bounds__(256) trsm_right_lower_kernel(TrsmBatch tb) {
   double* __restrict__ E = s.E;
   const double* __restrict__ L = s.L;
   const int64_t lde = s.lde, ldl = s.ldl;
-  // cooperative band-block load: thread t moves 8 consecutive doubles of row t / 8 (rows past the end are clamped: they
-  // only feed accumulator rows that are never stored)
-  const int xr = threadIdx.x >> 3, xc = (threadIdx.x & 7) * 8;
+  // cooperative band-block load: thread t moves TR_PA consecutive doubles of one row (rows past the end are clamped:
+  // they only feed accumulator rows that are never stored)
+  constexpr int TPR = 64 / TR_PA;  // threads per row
+  const int xr = threadIdx.x / TPR, xc = (threadIdx.x % TPR) * TR_PA;
   const double* xsrc = E + (int64_t)min(r0 + xr, rows - 1) * lde;
 
   for (int j = nblk - 1; j >= 0; --j) {
@@ -62,9 +65,9 @@ __global__ void __launch_bounds__(256) trsm_right_lower_kernel(TrsmBatch tb) {
     const int colw = j0 + 16 * w + l15;  // this lane's output column (b-operand column and accumulator column)
     const bool col_ok = colw < m;
     const int colc = min(colw, m - 1);
-    d4 acc[2];
+    d4 acc[TR_RT];
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
+    for (int rt = 0; rt < TR_RT; ++rt)
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
         const int row = r0 + 16 * rt + l4 + 4 * reg;
@@ -78,7 +81,7 @@ __global__ void __launch_bounds__(256) trsm_right_lower_kernel(TrsmBatch tb) {
     // starts with an L2 miss of 2-3 us, three times the 0.85 us the matrix pipe needs per pair): they are fetched THREE
     // pairs ahead into a ring of four register sets (no copies: the loop body is unrolled over the ring), and so are
     // the band blocks (32 MB of finished X at m = 2000: long evicted from the 4 MB L2 when they are needed again).
-    double b0[16], b1[16], b2[16], b3[16], pa0[8], pa1[8], pa2[8], pa3[8];
+    double b0[16], b1[16], b2[16], b3[16], pa0[TR_PA], pa1[TR_PA], pa2[TR_PA], pa3[TR_PA];
     auto gload_b = [&](int i, double (&B)[16]) {
       const int kb = i * NB + 16 * l4;
       if (i * NB + NB <= m) {
@@ -93,34 +96,34 @@ __global__ void __launch_bounds__(256) trsm_right_lower_kernel(TrsmBatch tb) {
         }
       }
     };
-    auto gload_a = [&](int i, double (&PA)[8]) {
+    auto gload_a = [&](int i, double (&PA)[TR_PA]) {
       const int i0 = i * NB;
       if (i0 + NB <= m) {
 #pragma unroll
-        for (int c = 0; c < 8; ++c) PA[c] = xsrc[i0 + xc + c];
+        for (int c = 0; c < TR_PA; ++c) PA[c] = xsrc[i0 + xc + c];
       } else {
 #pragma unroll
-        for (int c = 0; c < 8; ++c) PA[c] = xsrc[min(i0 + xc + c, m - 1)];
+        for (int c = 0; c < TR_PA; ++c) PA[c] = xsrc[min(i0 + xc + c, m - 1)];
       }
     };
-    auto sstore = [&](int buf, const double (&PA)[8]) {
+    auto sstore = [&](int buf, const double (&PA)[TR_PA]) {
 #pragma unroll
-      for (int c = 0; c < 8; ++c) Xs[buf][xr * TLD + xc + c] = PA[c];
+      for (int c = 0; c < TR_PA; ++c) Xs[buf][xr * TLD + xc + c] = PA[c];
     };
     // One pair.  Ring slot of pair i is (i - j - 1) mod 4 for both operands: multiply with Bcur (band block i is already
     // in LDS), refill the slot used one pair ago (Bfree) with factor block i + 3, refill this pair's band slot (Acur, its
     // block went to LDS one pair ago) with band block i + 4, and move band block i + 1 (Anext) to LDS at the end.
-    auto step = [&](int i, const double (&Bcur)[16], double (&Bfree)[16], double (&Acur)[8], const double (&Anext)[8]) {
+    auto step = [&](int i, const double (&Bcur)[16], double (&Bfree)[16], double (&Acur)[TR_PA],
+                    const double (&Anext)[TR_PA]) {
       const int cur = (i - j - 1) & 1;
       if (i + 3 < nblk) gload_b(i + 3, Bfree);
       if (i + 4 < nblk) gload_a(i + 4, Acur);
       const double* x0 = Xs[cur] + l15 * TLD + 16 * l4;
-      const double* x1 = x0 + 16 * TLD;
 #pragma unroll
-      for (int ks = 0; ks < 16; ++ks) {
-        acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(x0[ks], Bcur[ks], acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(x1[ks], Bcur[ks], acc[1], 0, 0, 0);
-      }
+      for (int ks = 0; ks < 16; ++ks)
+#pragma unroll
+        for (int rt = 0; rt < TR_RT; ++rt)
+          acc[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(x0[rt * 16 * TLD + ks], Bcur[ks], acc[rt], 0, 0, 0);
       if (i + 1 < nblk) sstore(cur ^ 1, Anext);
       __syncthreads();
     };
@@ -141,22 +144,23 @@ __global__ void __launch_bounds__(256) trsm_right_lower_kernel(TrsmBatch tb) {
     }
     // X_j = -acc * L_jj^-1: the accumulator goes through LDS to become an a-operand
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
+    for (int rt = 0; rt < TR_RT; ++rt)
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) T[(16 * rt + l4 + 4 * reg) * TLD + 16 * w + l15] = col_ok ? acc[rt][reg] : 0.0;
     __syncthreads();
     const double* __restrict__ D = s.Dinv + (size_t)j * NB * NB;
-    d4 out[2] = {d4{0.0, 0.0, 0.0, 0.0}, d4{0.0, 0.0, 0.0, 0.0}};
+    d4 out[TR_RT];
+#pragma unroll
+    for (int rt = 0; rt < TR_RT; ++rt) out[rt] = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks) {
-      const double bd = -D[(4 * ks + l4) * NB + 16 * w + l15];
-      const double t0 = T[l15 * TLD + 4 * ks + l4];
-      const double t1 = T[(16 + l15) * TLD + 4 * ks + l4];
-      out[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(t0, bd, out[0], 0, 0, 0);
-      out[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(t1, bd, out[1], 0, 0, 0);
+      const double bd = -D[(4 * ks + l4) * NB + 16 * w + l15];  // X_j = -acc L_jj^-1
+#pragma unroll
+      for (int rt = 0; rt < TR_RT; ++rt)
+        out[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(T[(16 * rt + l15) * TLD + 4 * ks + l4], bd, out[rt], 0, 0, 0);
     }
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
+    for (int rt = 0; rt < TR_RT; ++rt)
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
         const int row = r0 + 16 * rt + l4 + 4 * reg;
