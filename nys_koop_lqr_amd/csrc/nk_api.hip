@@ -741,6 +741,9 @@ static int fit_impl(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int6
   {
     SideScope prep(ctx, ctx->stream_prep);
     NK_HIP(hipStreamWaitEvent(ctx->stream, ev[8], 0));
+    // kernel matrices are positive semi-definite: the jitter bounds the smallest eigenvalue of K_mm + jitter I from
+    // below, which lets the iteration be queued before this factorisation has run (SqrtPlan::lambda_min_hint)
+    splan.lambda_min_hint = jitter > 0.0 ? jitter : 0.0;
     NK_TRY(sqrtm_prepare(ctx, Kj, m, m, &splan));
     NK_HIP(hipEventRecord(ev[9], ctx->stream));
   }
@@ -775,14 +778,8 @@ static int fit_impl(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int6
   // ---- ... while S = K_mm^{1/2}, S^{-1} (regressors.py:140,163) runs on the side stream (GEMM bound) --------------------
   int it = 0;
   double resid = 0.0;
-  {
-    SideScope side(ctx);
-    NK_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_fork, 0));
-    NK_HIP(hipStreamWaitEvent(ctx->stream, ev[9], 0));
-    NK_HIP(hipEventRecord(ev[6], ctx->stream));
-    NK_TRY(sqrtm_finish(ctx, &splan, mdl->S, mdl->Sinv));
-    NK_HIP(hipEventRecord(ev[7], ctx->stream));
-    // still on the side stream (the factorisation chain is usually not finished yet): S^-T and K_xo S^-1
+  // products that depend on the square root only (current stream)
+  auto sqrt_products = [&]() -> int {
     NK_TRY(launch_transpose(ctx, mdl->Sinv, m, Sinvt, m, m, m));
     if (same_centers) {
       // K_xo = K_mm = S^2 - jitter I, hence K_xo S^-1 = S - jitter S^-1: no product (and a smaller rounding error than
@@ -793,6 +790,17 @@ static int fit_impl(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int6
       NK_TRY(launch_transpose(ctx, Kxo, m, X1, m, m, m));
       NK_TRY(launch_gemm(ctx, true, false, m, m, m, 1.0, X1, m, mdl->Sinv, m, 0.0, T1t, m));
     }
+    return NK_OK;
+  };
+  {
+    SideScope side(ctx);
+    NK_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_fork, 0));
+    NK_HIP(hipStreamWaitEvent(ctx->stream, ev[9], 0));
+    NK_HIP(hipEventRecord(ev[6], ctx->stream));
+    NK_TRY(sqrtm_finish(ctx, &splan, mdl->S, mdl->Sinv));
+    NK_HIP(hipEventRecord(ev[7], ctx->stream));
+    // still on the side stream (the factorisation chain is usually not finished yet): S^-T and K_xo S^-1
+    NK_TRY(sqrt_products());
     NK_HIP(hipEventRecord(ctx->ev_join, ctx->stream));
   }
   NK_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
@@ -804,20 +812,36 @@ static int fit_impl(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int6
   // ---- operator products; every product is P^T Q with P stored contraction-major (fast TN engine) -----------------------
   //   [A B] = S^-1 (cross inner^-1) blkdiag(K_xo S^-1, I)   with  cross inner^-1 = [V1^T | V2^T] in G2
   //   (T1t holds K_xo S^-1, computed on the side stream)
-  NK_TRY(launch_transpose(ctx, G2, mp, V1, m, m, m));                                         // V1 (m x m)
-  NK_TRY(launch_gemm(ctx, true, false, m, m, m, 1.0, V1, m, T1t, m, 0.0, X1, m));             // X1 = V1^T (K_xo S^-1)
-  NK_TRY(launch_gemm(ctx, true, false, m, m, m, 1.0, Sinvt, m, X1, m, 0.0, mdl->A, mp));      // A = S^-1 X1
-  if (p > 0) NK_TRY(launch_gemm(ctx, true, false, m, p, m, 1.0, Sinvt, m, G2 + m, mp, 0.0, mdl->B, mp));  // B = S^-1 V2^T
-  //   C = (left_rec inner_rec^-1) S : C^T = S^T Wc with Wc = G4^T
-  NK_TRY(launch_transpose(ctx, G4, m, Wc, ldd, d, m));
-  NK_TRY(launch_gemm(ctx, true, false, m, d, m, 1.0, mdl->S, m, Wc, ldd, 0.0, Ct, ldd));      // C^T = S^T Wc
-  NK_TRY(launch_transpose(ctx, Ct, ldd, mdl->C, m, m, d));
-  NK_TRY(launch_gemm(ctx, true, false, d, mp, m, 1.0, Ct, ldd, mdl->A, mp, 0.0, mdl->W, mp));  // W = C G (:167)
+  auto operator_products = [&]() -> int {
+    NK_TRY(launch_transpose(ctx, G2, mp, V1, m, m, m));                                         // V1 (m x m)
+    NK_TRY(launch_gemm(ctx, true, false, m, m, m, 1.0, V1, m, T1t, m, 0.0, X1, m));             // X1 = V1^T (K_xo S^-1)
+    NK_TRY(launch_gemm(ctx, true, false, m, m, m, 1.0, Sinvt, m, X1, m, 0.0, mdl->A, mp));      // A = S^-1 X1
+    if (p > 0) NK_TRY(launch_gemm(ctx, true, false, m, p, m, 1.0, Sinvt, m, G2 + m, mp, 0.0, mdl->B, mp));  // B = S^-1 V2^T
+    //   C = (left_rec inner_rec^-1) S : C^T = S^T Wc with Wc = G4^T
+    NK_TRY(launch_transpose(ctx, G4, m, Wc, ldd, d, m));
+    NK_TRY(launch_gemm(ctx, true, false, m, d, m, 1.0, mdl->S, m, Wc, ldd, 0.0, Ct, ldd));      // C^T = S^T Wc
+    NK_TRY(launch_transpose(ctx, Ct, ldd, mdl->C, m, m, d));
+    NK_TRY(launch_gemm(ctx, true, false, d, mp, m, 1.0, Ct, ldd, mdl->A, mp, 0.0, mdl->W, mp));  // W = C G (:167)
+    return NK_OK;
+  };
+  NK_TRY(operator_products());
   NK_HIP(hipEventRecord(ev[5], ctx->stream));
   tr.mark("solve issued");
   NK_TRY(cholesky_check_pair(ctx, sys, 2));  // synchronises the main stream (which has joined the side stream)
   tr.mark("final sync");
-  NK_TRY(sqrtm_verdict(ctx, &splan, &it, &resid));  // the iteration was queued without host round trips
+  {
+    const int vr = sqrtm_verdict(ctx, &splan, &it, &resid);  // the iteration was queued without host round trips
+    if (vr == NK_SQRT_RETRY) {
+      // K_mm + jitter I is not positive definite to working precision (or the eigenvalue bound did not hold): the
+      // coupled iteration needs no factorisation; then everything that depends on the square root once more
+      NK_TRY(sqrtm_spd_coupled(ctx, Kj, m, m, mdl->S, mdl->Sinv, &it, &resid));
+      NK_TRY(sqrt_products());
+      NK_TRY(operator_products());
+      NK_HIP(hipStreamSynchronize(ctx->stream));
+    } else {
+      NK_TRY(vr);
+    }
+  }
   mdl->has_ops = true;
 
   if (stats) {

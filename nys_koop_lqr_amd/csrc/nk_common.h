@@ -187,7 +187,15 @@ struct SqrtPlan {
   bool deferred = false;
   int rc = 0, iters = 0, kmax = 0;
   double resid = 0.0;
+  // Optional rigorous lower bound of the smallest eigenvalue of P known to the caller (the jitter of K_mm + jitter I):
+  // with it the step budget needs nothing from the factorisation, so sqrtm_finish queues the iteration without waiting
+  // for sqrtm_prepare's kernels (`early`); a failed factorisation or an exhausted budget then surfaces in
+  // sqrtm_verdict as NK_SQRT_RETRY and the caller falls back to sqrtm_spd_coupled.
+  double lambda_min_hint = 0.0;
+  bool early = false;
 };
+constexpr int NK_SQRT_RETRY = 1;  // internal (positive) verdict: redo the square root with the coupled iteration
+int sqrtm_spd_coupled(nk_ctx* ctx, const double* P, int64_t ldp, int m, double* S, double* Sinv, int* iters, double* resid);
 int sqrtm_prepare(nk_ctx* ctx, const double* P, int64_t ldp, int m, SqrtPlan* plan);
 int sqrtm_finish(nk_ctx* ctx, SqrtPlan* plan, double* S, double* Sinv);
 // after the stream that ran sqrtm_finish has been synchronised: NK_OK / NK_ERR_NO_CONVERGENCE, iteration count, residual

@@ -262,8 +262,8 @@ static int read_scalar(nk_ctx* ctx, const double* d_ptr, double* out) {
   return NK_OK;
 }
 
-static int sqrtm_spd_coupled(nk_ctx* ctx, const double* P, int64_t ldp, int m, double* S, double* Sinv, int* iters,
-                             double* resid) {
+int sqrtm_spd_coupled(nk_ctx* ctx, const double* P, int64_t ldp, int m, double* S, double* Sinv, int* iters,
+                      double* resid) {
   const ArenaMark mk = arena_mark(ctx);
   const size_t mm = (size_t)m * m;
   double *Y = nullptr, *Z = nullptr, *Yn = nullptr, *Zn = nullptr, *M = nullptr, *T = nullptr;
@@ -649,6 +649,9 @@ int sqrtm_prepare(nk_ctx* ctx, const double* P, int64_t ldp, int m, SqrtPlan* pl
     NK_HIP(hipGetLastError());
     arena_release(ctx, mk);
   }
+  // the three scalars of the scaling schedule are on the host long before the iteration is queued
+  NK_HIP(hipMemcpyAsync(ctx->h_scalars + 12, plan->d_sc, 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  NK_HIP(hipEventRecord(ctx->ev[11], ctx->stream));
   double* E = plan->W + mm;
   NK_TRY(launch_copy2d(ctx, P, ldp, plan->W, m, m, m));
   NK_TRY(launch_fill(ctx, E, m, m, m, 0.0));
@@ -718,11 +721,23 @@ int sqrtm_finish(nk_ctx* ctx, SqrtPlan* plan, double* S, double* Sinv) {
   const int ib = info_base(ctx);
   plan->deferred = false;
   plan->rc = NK_OK; plan->iters = 0; plan->resid = 0.0;
-  NK_HIP(hipMemcpyAsync(ctx->h_scalars, plan->d_sc, 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  NK_HIP(hipMemcpyAsync(ctx->h_info + ib, ctx->d_info + ib, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-  NK_HIP(hipStreamSynchronize(ctx->stream));  // the one host round trip of the square root
-  const double c = ctx->h_scalars[0], sumsq = ctx->h_scalars[1], trace = ctx->h_scalars[2], linv2 = ctx->h_scalars[3];
-  if (ctx->h_info[ib] != 0 || !(c > 0.0) || !std::isfinite(c) || !(linv2 > 0.0) || !std::isfinite(linv2)) {
+  // With a caller-supplied eigenvalue bound (large aligned matrices) nothing of the factorisation is needed to queue the
+  // iteration: the host only waits for the three schedule scalars, copied right at the start of sqrtm_prepare.
+  plan->early = plan->lambda_min_hint > 0.0 && m >= 1024 && m % 2 == 0;
+  double c, sumsq, trace, linv2 = 0.0;
+  if (plan->early) {
+    NK_HIP(hipEventSynchronize(ctx->ev[11]));
+    c = ctx->h_scalars[12]; sumsq = ctx->h_scalars[13]; trace = ctx->h_scalars[14];
+    if (!(c > 0.0) || !std::isfinite(c)) plan->early = false;
+  }
+  if (!plan->early) {
+    NK_HIP(hipMemcpyAsync(ctx->h_scalars, plan->d_sc, 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    NK_HIP(hipMemcpyAsync(ctx->h_info + ib, ctx->d_info + ib, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    NK_HIP(hipStreamSynchronize(ctx->stream));  // the one host round trip of the square root
+    c = ctx->h_scalars[0]; sumsq = ctx->h_scalars[1]; trace = ctx->h_scalars[2]; linv2 = ctx->h_scalars[3];
+  }
+  if (!plan->early &&
+      (ctx->h_info[ib] != 0 || !(c > 0.0) || !std::isfinite(c) || !(linv2 > 0.0) || !std::isfinite(linv2))) {
     // not numerically positive definite for the Cholesky route (e.g. a rank-deficient kernel matrix with a jitter below
     // the rounding level): the coupled iteration needs no factorisation
     arena_release(ctx, plan->mark);
@@ -767,6 +782,10 @@ int sqrtm_finish(nk_ctx* ctx, SqrtPlan* plan, double* S, double* Sinv) {
   // the rigorous step budget adds (about five at m = 500, six launches each) would cost more than the few
   // synchronisations of the host-checked loop below.
   const bool queued = fast && m >= 1024;
+  if (plan->early && !queued) {  // cannot happen for the shapes `early` is set for; keep the contract simple
+    set_error("sqrtm: internal: early queueing needs the LDS-DMA path");
+    return NK_ERR_BAD_ARG;
+  }
 
   if (queued) {
     // ---- the whole iteration is queued without host round trips.  The step count is data dependent, so (a) a rigorous
@@ -779,7 +798,8 @@ int sqrtm_finish(nk_ctx* ctx, SqrtPlan* plan, double* S, double* Sinv) {
     int kmax = 0;
     {
       double a = a_lo, b = b_hi;                   // schedule (from the over-estimate, as before)
-      double ta = 0.5 / (c * linv2), tb = 1.0;     // true interval: [lower bound / 2, 1]
+      // true interval: [lower bound / 2, 1]; the bound is the caller's (jitter) or 1 / ||L^-1||_F^2
+      double ta = plan->early ? 0.5 * plan->lambda_min_hint / c : 0.5 / (c * linv2), tb = 1.0;
       if (ta > a) ta = a;
       int kconv = -1;
       for (int k = 0; k < 100; ++k) {
@@ -830,6 +850,8 @@ int sqrtm_finish(nk_ctx* ctx, SqrtPlan* plan, double* S, double* Sinv) {
     // X_j lives in Xa for odd j and in Xb for even j; the step count state[0] = j picks the operand on the device
     NK_TRY(sqrtm_polar_products(ctx, plan, Xa, T, c, S, Sinv, Xb, state));
     NK_HIP(hipMemcpyAsync(ctx->h_scalars + 8, state, 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (plan->early)  // the verdict of the factorisation travels with the verdict of the iteration
+      NK_HIP(hipMemcpyAsync(ctx->h_info + ib, ctx->d_info + ib, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     plan->deferred = true;
     plan->kmax = kmax;
     arena_release(ctx, plan->mark);
@@ -898,7 +920,11 @@ int sqrtm_verdict(nk_ctx* ctx, SqrtPlan* plan, int* iters, double* resid) {
   if (plan->deferred) {
     const double flag = ctx->h_scalars[8];
     plan->deferred = false;
-    if (flag == 0.0 || !std::isfinite(ctx->h_scalars[10])) {
+    if (plan->early && (ctx->h_info[2] != 0 || flag == 0.0 || !std::isfinite(ctx->h_scalars[10]))) {
+      plan->iters = plan->kmax;
+      plan->resid = ctx->h_scalars[10];
+      plan->rc = NK_SQRT_RETRY;
+    } else if (flag == 0.0 || !std::isfinite(ctx->h_scalars[10])) {
       plan->iters = plan->kmax;
       plan->resid = ctx->h_scalars[10];
       plan->rc = NK_ERR_NO_CONVERGENCE;

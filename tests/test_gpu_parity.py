@@ -606,3 +606,41 @@ def test_indefinite_system_is_reported_not_computed(nk, O, golden):
     assert bad._model is None
     reg, X, Y, d = _fit(nk, O, "rbf", g, 6)  # same context, next call
     assert relf(reg.A, g["A"]) < 1e-6
+
+
+@pytest.mark.gpu
+def test_fit_with_vanishing_jitter_takes_the_fallback_or_fails_cleanly(nk, O):
+    """m >= 1024 with a positive jitter queues the square-root iteration before the factorisation of K_mm has run
+    (the jitter bounds the spectrum).  With a jitter below rounding level that factorisation fails: the verdict at the
+    end of the call sends the fit through the coupled iteration instead, or the call fails with a clean error; either
+    way the context stays usable and a normal fit of the same shape is unaffected."""
+    rng = np.random.default_rng(5)
+    n, d, p, m = 3000, 8, 2, 1024
+    S = rng.standard_normal((n, d))
+    U = rng.standard_normal((n, p))
+    Y = np.tanh(S @ (rng.standard_normal((d, d)) / np.sqrt(d))) + 0.1 * U @ rng.standard_normal((p, d))
+    X = np.hstack([S, U])
+    idx = rng.choice(n, m, replace=False)
+
+    kern = nk.ThreeDimensionalKernel(6.0, 6.0, 6.0, 9)
+    good = nk.KoopmanNystromRegressor(p, kernel=kern, gamma=1e-4, m=m)
+    Y9 = np.hstack([Y, Y[:, :1]])  # d = 9: a multiple of 3 for the x/y/z lengthscale pattern
+    X9 = np.hstack([S, S[:, :1], U])
+    good.nystrom_centers_output = Y9.T[:, idx]
+    good.fit(X9, Y9)
+    ref = O.KoopmanNystromOracle(p, kernel=O.ThreeDimensionalKernel(6.0, 6.0, 6.0, 9), gamma=1e-4, m=m, faithful=False)
+    ref.nystrom_centers_output = Y9.T[:, idx]
+    ref.fit(X9, Y9)
+    assert relf(good.predict(X9[:50]), ref.predict(X9[:50])) < 1e-6 and good.fit_stats_["sqrt_iters"] > 3
+    bad = nk.KoopmanNystromRegressor(p, kernel=kern, gamma=1e-4, m=m)
+    bad.jitter = 1e-22
+    bad.nystrom_centers_output = Y9.T[:, idx]
+    try:
+        bad.fit(X9, Y9)
+        assert np.all(np.isfinite(bad.A)) and np.all(np.isfinite(bad.weights))
+    except (np.linalg.LinAlgError, RuntimeError):
+        assert bad._model is None
+    again = nk.KoopmanNystromRegressor(p, kernel=kern, gamma=1e-4, m=m)
+    again.nystrom_centers_output = Y9.T[:, idx]
+    again.fit(X9, Y9)
+    assert np.array_equal(again.A, good.A)
