@@ -677,14 +677,24 @@ int sqrtm_prepare(nk_ctx* ctx, const double* P, int64_t ldp, int m, SqrtPlan* pl
   return NK_OK;
 }
 
-// convergence bookkeeping of the queued iteration (one thread): state[0] = step + 1 of the first step whose residual is
-// below 1e-7 (0: not yet), state[1] = that residual, state[2] = last residual seen
-__global__ void ns_flag_kernel(const double* __restrict__ r2, int m, int step, double* __restrict__ state) {
-  const double r = sqrt(r2[0] / m);
-  state[2] = r;
-  if (state[0] == 0.0 && r < 1e-7) {
-    state[0] = (double)(step + 1);
-    state[1] = r;
+// convergence bookkeeping of the queued iteration: fixed-order sum of the per-block partials of sum (M - I)^2, then
+// state[0] = step + 1 of the first step whose residual is below 1e-7 (0: not yet), state[1] = that residual,
+// state[2] = last residual seen
+__global__ void __launch_bounds__(256) ns_flag_kernel(const double* __restrict__ partial, int count, int m, int step,
+                                                      double* __restrict__ state) {
+  __shared__ double sh[4];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < count; i += blockDim.x) s += partial[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double r = sqrt((sh[0] + sh[1] + sh[2] + sh[3]) / m);
+    state[2] = r;
+    if (state[0] == 0.0 && r < 1e-7) {
+      state[0] = (double)(step + 1);
+      state[1] = r;
+    }
   }
 }
 
@@ -799,7 +809,7 @@ int sqrtm_finish(nk_ctx* ctx, SqrtPlan* plan, double* S, double* Sinv) {
     {
       double a = a_lo, b = b_hi;                   // schedule (from the over-estimate, as before)
       // true interval: [lower bound / 2, 1]; the bound is the caller's (jitter) or 1 / ||L^-1||_F^2
-      double ta = plan->early ? 0.5 * plan->lambda_min_hint / c : 0.5 / (c * linv2), tb = 1.0;
+      double ta = plan->early ? 0.9 * plan->lambda_min_hint / c : 0.5 / (c * linv2), tb = 1.0;
       if (ta > a) ta = a;
       int kconv = -1;
       for (int k = 0; k < 100; ++k) {
@@ -815,6 +825,8 @@ int sqrtm_finish(nk_ctx* ctx, SqrtPlan* plan, double* S, double* Sinv) {
     }
     double* state = plan->d_sc + 5;
     NK_HIP(hipMemsetAsync(state, 0, 3 * sizeof(double), ctx->stream));
+    double* rpart = nullptr;
+    NK_TRY(arena_alloc_t(ctx, (size_t)grid_for((int64_t)m * m, ctx->num_cu), &rpart));
     for (int k = 0; k < kmax; ++k) {
       TnSkip skip;
       skip.state = state; skip.step = k;
@@ -830,8 +842,11 @@ int sqrtm_finish(nk_ctx* ctx, SqrtPlan* plan, double* S, double* Sinv) {
         NK_TRY(launch_gemm_tn_multi(ctx, &pm, 1, m, 0, nullptr, true, &skip));
       }
       if (checks[k]) {
-        NK_TRY(launch_frob_minus_identity(ctx, M, m, m, ctx->d_scalars, &skip));
-        hipLaunchKernelGGL(ns_flag_kernel, dim3(1), dim3(1), 0, ctx->stream, ctx->d_scalars, m, k, state);
+        // residual partials (one launch), then their sum and the convergence flag (one launch)
+        const int blocks = grid_for((int64_t)m * m, ctx->num_cu);
+        hipLaunchKernelGGL(frob_mi_partial_kernel, dim3(blocks), dim3(256), 0, ctx->stream, M, (int64_t)m, m, rpart,
+                           skip.state, skip.step);
+        hipLaunchKernelGGL(ns_flag_kernel, dim3(1), dim3(256), 0, ctx->stream, rpart, blocks, m, k, state);
         NK_HIP(hipGetLastError());
       }
       if (k == 0) {
