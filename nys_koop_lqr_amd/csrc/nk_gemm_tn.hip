@@ -16,6 +16,9 @@
 //     applies alpha/beta, bounds and the symmetric mirror (deterministic; no float atomics).
 #include "nk_common.h"
 
+#include <cstdlib>
+#include <cstring>
+
 namespace nk {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
@@ -73,6 +76,59 @@ __device__ __forceinline__ void dma_row(const double* gsrc, double* lds_row) {
                                    (__attribute__((address_space(3))) void*)lds_row, 16, 0, 0);
 }
 
+__device__ int g_sb_order = 1;
+// tile (tm, tn) of index t within a problem.  Full problems whose tile grid is a multiple of 8 x 8 are walked in 8 x 8
+// super-blocks: workgroups are dispatched in index order, so the ~64 tiles an XCD holds at a time then stream 8 + 8
+// operand panels instead of 4 + 16, and more of the panel traffic is shared through that XCD's L2.
+__device__ __forceinline__ void tn_tile_coords(int t, int tri, int tiles_n, int M, int& tm, int& tn) {
+  if (tri == TRI_FULL) {
+    const int tiles_m = (M + TBM - 1) / TBM;
+    if (g_sb_order && (tiles_m & 7) == 0 && (tiles_n & 7) == 0) {
+      const int sb = t >> 6, w = t & 63;
+      const int sbn = tiles_n >> 3;
+      const int sbr = sb / sbn, sbc = sb - sbr * sbn;
+      tm = sbr * 8 + (w >> 3);
+      tn = sbc * 8 + (w & 7);
+    } else {
+      tm = t / tiles_n;
+      tn = t - tm * tiles_n;
+    }
+  } else if (g_sb_order && (tiles_n & 7) == 0) {
+    // upper triangle in 8 x 8 super-blocks (I <= J, row-major over the super-blocks): 36 tiles in a diagonal super-block
+    // (its own upper triangle, row-major), 64 in the others
+    const int S = tiles_n >> 3;
+    int I = 0, J = 0, rem = t;
+    for (;;) {
+      const int cnt = (I == J) ? 36 : 64;
+      if (rem < cnt) break;
+      rem -= cnt;
+      if (++J == S) { ++I; J = I; }
+    }
+    int r, c;
+    if (I == J) {
+      r = 0;
+      while (rem >= 8 - r) {
+        rem -= 8 - r;
+        ++r;
+      }
+      c = r + rem;
+    } else {
+      r = rem >> 3;
+      c = rem & 7;
+    }
+    tm = I * 8 + r;
+    tn = J * 8 + c;
+  } else {  // upper triangle, row-major enumeration
+    int row = 0, rem = t;
+    while (rem >= tiles_n - row) {
+      rem -= tiles_n - row;
+      ++row;
+    }
+    tm = row;
+    tn = row + rem;
+  }
+}
+
 template <int EPI>
 __device__ __forceinline__ void tn_body(const TnParams& P) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -95,19 +151,7 @@ __device__ __forceinline__ void tn_body(const TnParams& P) {
     tn = xcd + 8 * (i - tm * cols);
     if (tm * TBM >= pr.M) return;
   } else {
-    const int t = gt - pr.tile_begin;
-    if (pr.tri == TRI_FULL) {
-      tm = t / pr.tiles_n;
-      tn = t - tm * pr.tiles_n;
-    } else {  // upper triangle, row-major enumeration
-      int row = 0, rem = t;
-      while (rem >= pr.tiles_n - row) {
-        rem -= pr.tiles_n - row;
-        ++row;
-      }
-      tm = row;
-      tn = row + rem;
-    }
+    tn_tile_coords(gt - pr.tile_begin, pr.tri, pr.tiles_n, pr.M, tm, tn);
   }
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -303,21 +347,7 @@ __global__ void __launch_bounds__(256) gemm_tn_reduce_kernel(TnRedParams P) {
     if (q < P.nprob && gt >= P.p[q].tile_begin) pi = q;
   const TnRed pr = P.p[pi];
   int tm, tn;
-  {
-    const int t = gt - pr.tile_begin;
-    if (pr.tri == TRI_FULL) {
-      tm = t / pr.tiles_n;
-      tn = t - tm * pr.tiles_n;
-    } else {
-      int row = 0, rem = t;
-      while (rem >= pr.tiles_n - row) {
-        rem -= pr.tiles_n - row;
-        ++row;
-      }
-      tm = row;
-      tn = row + rem;
-    }
-  }
+  tn_tile_coords(gt - pr.tile_begin, pr.tri, pr.tiles_n, pr.M, tm, tn);
   typedef double d2 __attribute__((ext_vector_type(2)));
   const double* base = P.slab + (int64_t)gt * P.splitk * (TBM * TBM) + part * (16 * TBM) + threadIdx.x * 2;
   d2 s[4];
@@ -399,6 +429,7 @@ bool tn_fast_ok(const TnProblem& p) {
 }
 
 static bool g_tn_attr_set = false;
+static bool g_sb_init = false;
 
 static int ensure_zero_page(nk_ctx* ctx) {
   if (ctx->d_zeros) return NK_OK;
@@ -475,6 +506,12 @@ int launch_gemm_tn_multi(nk_ctx* ctx, const TnProblem* probs, int nprob, int64_t
   P.skip_state = R.skip_state = skip ? skip->state : nullptr;
   P.skip_step = R.skip_step = skip ? skip->step : 0;
   P.select_state = skip ? skip->select : nullptr;
+  if (!g_sb_init) {
+    const char* e = getenv("NYSKOOP_TILE_ORDER");
+    int v = (e && strcmp(e, "row") == 0) ? 0 : 1;
+    NK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_sb_order), &v, sizeof(int)));
+    g_sb_init = true;
+  }
   if (!g_tn_attr_set) {
     NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_f64_kernel<0>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES));
