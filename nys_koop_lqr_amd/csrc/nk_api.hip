@@ -621,10 +621,16 @@ static int fit_impl(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int6
   for (auto& ps : passes) for (auto& pc : ps) maxlen = std::max(maxlen, pc.len);
   const int64_t ldt = (maxlen + 1) & ~(int64_t)1, ldzt = (m + 1) & ~1;
   double *center = nullptr, *Rt = nullptr, *sqr = nullptr, *Zto = nullptr, *sqzo = nullptr, *Zti = nullptr, *sqzi = nullptr;
+  double *Rt2 = nullptr, *sqr2 = nullptr;
+  const bool overlap_prep = gram_form && passes.size() == 1 && passes[0].size() == 1;
   if (gram_form) {
     NK_TRY(arena_alloc_t(ctx, (size_t)d, &center));
     NK_TRY(arena_alloc_t(ctx, (size_t)d * ldt, &Rt));
     NK_TRY(arena_alloc_t(ctx, (size_t)maxlen, &sqr));
+    if (overlap_prep) {
+      NK_TRY(arena_alloc_t(ctx, (size_t)d * ldt, &Rt2));
+      NK_TRY(arena_alloc_t(ctx, (size_t)maxlen, &sqr2));
+    }
     NK_TRY(arena_alloc_t(ctx, (size_t)d * ldzt, &Zto));
     NK_TRY(arena_alloc_t(ctx, (size_t)m, &sqzo));
     if (kd->type == NK_KERNEL_LINEAR) NK_TRY(launch_fill(ctx, center, d, 1, d, 0.0));  // x.y is not shift invariant
@@ -647,7 +653,22 @@ static int fit_impl(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int6
     for (const Piece& pc : ps) {
       const double* xs = x.ptr + pc.b * x.ld;
       const double* ys = y.ptr + pc.b * y.ld;
-      if (gram_form) {
+      if (gram_form && overlap_prep) {
+        // single piece: the (HBM-bound) preparation of the Y rows runs on the side stream beside the (MFMA-bound) kernel
+        // block of the X rows, into its own scratch
+        NK_HIP(hipEventRecord(ev[12], ctx->stream));  // landmarks, centre and the staged data are ready
+        {
+          SideScope side(ctx);
+          NK_HIP(hipStreamWaitEvent(ctx->stream, ev[12], 0));
+          NK_TRY(prep_rows(ctx, ys, y.ld, pc.len, d, mdl->winv, center, Rt2, ldt, sqr2));
+          NK_HIP(hipEventRecord(ev[13], ctx->stream));
+        }
+        NK_TRY(prep_rows(ctx, xs, x.ld, pc.len, d, mdl->winv, center, Rt, ldt, sqr));
+        NK_TRY(launch_kmat_gram(ctx, kd->type, Rt, ldt, sqr, pc.len, Zti, ldzt, sqzi, m, d, kd->sigma0, F + o * ldf, ldf));
+        NK_HIP(hipStreamWaitEvent(ctx->stream, ev[13], 0));
+        NK_TRY(launch_kmat_gram(ctx, kd->type, Rt2, ldt, sqr2, pc.len, Zto, ldzt, sqzo, m, d, kd->sigma0,
+                                F + o * ldf + off_out, ldf));
+      } else if (gram_form) {
         NK_TRY(prep_rows(ctx, xs, x.ld, pc.len, d, mdl->winv, center, Rt, ldt, sqr));
         NK_TRY(launch_kmat_gram(ctx, kd->type, Rt, ldt, sqr, pc.len, Zti, ldzt, sqzi, m, d, kd->sigma0, F + o * ldf, ldf));
         NK_TRY(prep_rows(ctx, ys, y.ld, pc.len, d, mdl->winv, center, Rt, ldt, sqr));
