@@ -76,14 +76,13 @@ __device__ __forceinline__ void dma_row(const double* gsrc, double* lds_row) {
                                    (__attribute__((address_space(3))) void*)lds_row, 16, 0, 0);
 }
 
-__device__ int g_sb_order = 1;
 // tile (tm, tn) of index t within a problem.  Full problems whose tile grid is a multiple of 8 x 8 are walked in 8 x 8
 // super-blocks: workgroups are dispatched in index order, so the ~64 tiles an XCD holds at a time then stream 8 + 8
 // operand panels instead of 4 + 16, and more of the panel traffic is shared through that XCD's L2.
 __device__ __forceinline__ void tn_tile_coords(int t, int tri, int tiles_n, int M, int& tm, int& tn) {
   if (tri == TRI_FULL) {
     const int tiles_m = (M + TBM - 1) / TBM;
-    if (g_sb_order && (tiles_m & 7) == 0 && (tiles_n & 7) == 0) {
+    if ((tiles_m & 7) == 0 && (tiles_n & 7) == 0) {
       const int sb = t >> 6, w = t & 63;
       const int sbn = tiles_n >> 3;
       const int sbr = sb / sbn, sbc = sb - sbr * sbn;
@@ -93,7 +92,7 @@ __device__ __forceinline__ void tn_tile_coords(int t, int tri, int tiles_n, int 
       tm = t / tiles_n;
       tn = t - tm * tiles_n;
     }
-  } else if (g_sb_order && (tiles_n & 7) == 0) {
+  } else if ((tiles_n & 7) == 0) {
     // upper triangle in 8 x 8 super-blocks (I <= J, row-major over the super-blocks): 36 tiles in a diagonal super-block
     // (its own upper triangle, row-major), 64 in the others
     const int S = tiles_n >> 3;
@@ -429,7 +428,6 @@ bool tn_fast_ok(const TnProblem& p) {
 }
 
 static bool g_tn_attr_set = false;
-static bool g_sb_init = false;
 
 static int ensure_zero_page(nk_ctx* ctx) {
   if (ctx->d_zeros) return NK_OK;
@@ -506,12 +504,6 @@ int launch_gemm_tn_multi(nk_ctx* ctx, const TnProblem* probs, int nprob, int64_t
   P.skip_state = R.skip_state = skip ? skip->state : nullptr;
   P.skip_step = R.skip_step = skip ? skip->step : 0;
   P.select_state = skip ? skip->select : nullptr;
-  if (!g_sb_init) {
-    const char* e = getenv("NYSKOOP_TILE_ORDER");
-    int v = (e && strcmp(e, "row") == 0) ? 0 : 1;
-    NK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_sb_order), &v, sizeof(int)));
-    g_sb_init = true;
-  }
   if (!g_tn_attr_set) {
     NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_f64_kernel<0>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES));
