@@ -203,6 +203,7 @@ def main():
                                    "l=20 gamma=1e-6 jitter=1e-6%s" % (n, m, d, p, "" if world == 1 else
                                                                       "; per-rank CV-grid candidates l in {10,20,40} x gamma in {1e-7..1e-3}"),
                        "n": n, "m": m, "d": d, "p": p, "inputs": "HBM-resident (device pointers through the C-ABI)",
+                       "outputs": "A,B,C,W copied to page-locked host arrays by asynchronous DMA that overlaps the next fit; all copies complete inside the timed region",
                        "parallelism": "1 process/GPU, independent fits per rank, RCCL all-gather of per-fit scalars",
                        "concurrent_fits_per_gpu": conc},
             "stages_ms": {k: avg(k) for k in ("ms_total", "ms_kmat", "ms_gram", "ms_sqrt", "ms_solve", "host_ms_drop",
