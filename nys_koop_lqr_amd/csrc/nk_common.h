@@ -224,7 +224,8 @@ int cholesky_lower_pair(nk_ctx* ctx, const CholSys* sys, int nsys);
 int cholesky_lower_pair_async(nk_ctx* ctx, const CholSys* sys, int nsys);  // no host synchronisation
 int cholesky_check_pair(nk_ctx* ctx, const CholSys* sys, int nsys);       // verdict of the async factorisation
 int cholesky_solve_pair(nk_ctx* ctx, const CholSys* sys, int nsys);
-int cholesky_aug_pair_async(nk_ctx* ctx, const CholSys* sys, int nsys);  // factor + both substitutions, no host sync
+// factor + both substitutions, no host sync; mark / mark_step: optional event recorded after block step `mark_step`
+int cholesky_aug_pair_async(nk_ctx* ctx, const CholSys* sys, int nsys, hipEvent_t mark = nullptr, int mark_step = -1);
 constexpr int CHOL_NB = 64;
 // trailing update C -= P P^T (K = 64) of up to two systems (nk_trail.hip); false: not that shape, use launch_gemm_pair
 bool launch_chol_trail_pair(nk_ctx* ctx, const GemmCall* calls, int ncalls, int* rc);

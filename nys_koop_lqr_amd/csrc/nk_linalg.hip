@@ -481,7 +481,7 @@ int cholesky_lower_pair(nk_ctx* ctx, const CholSys* sys, int nsys) {
 // those rows.  Per block step: potrf (both systems), panel, trailing; the backward pass is a single launch in which
 // every workgroup carries a band of rows through the whole substitution.  The separate forward substitution
 // (2 launches per block) disappears.
-int cholesky_aug_pair_async(nk_ctx* ctx, const CholSys* sys, int nsys) {
+int cholesky_aug_pair_async(nk_ctx* ctx, const CholSys* sys, int nsys, hipEvent_t mark, int mark_step) {
   constexpr int NB = CHOL_NB;
   NK_REQUIRE(nsys >= 1 && nsys <= 2, "cholesky_aug_pair: 1..2 systems");
   NK_HIP(hipMemsetAsync(ctx->d_info + info_base(ctx), 0, 2 * sizeof(int), ctx->stream));
@@ -523,6 +523,7 @@ int cholesky_aug_pair_async(nk_ctx* ctx, const CholSys* sys, int nsys) {
       if (!launch_chol_trail_pair(ctx, trail, nsys, &rc_trail)) NK_TRY(launch_gemm_pair(ctx, false, true, trail, nsys));
       NK_TRY(rc_trail);
     }
+    if (mark != nullptr && (jb == mark_step || (jb == nblk - 1 && mark_step >= nblk))) NK_HIP(hipEventRecord(mark, ctx->stream));
   }
   // backward on the extra rows E (extra x m, now holding (L^-1 R)^T):  E <- E L^-1, one launch (nk_trsm.hip)
   NK_TRY(launch_trsm_right_lower_pair(ctx, sys, nsys));
