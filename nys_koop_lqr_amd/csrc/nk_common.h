@@ -229,6 +229,8 @@ int cholesky_aug_pair_async(nk_ctx* ctx, const CholSys* sys, int nsys, hipEvent_
 constexpr int CHOL_NB = 64;
 // trailing update C -= P P^T (K = 64) of up to two systems (nk_trail.hip); false: not that shape, use launch_gemm_pair
 bool launch_chol_trail_pair(nk_ctx* ctx, const GemmCall* calls, int ncalls, int* rc);
+// panel product P <- P Linv_jj^T (64 x 64) of up to two systems (nk_trail.hip); false: not that shape
+bool launch_chol_panel_pair(nk_ctx* ctx, const GemmCall* calls, int ncalls, int* rc);
 // E_q <- E_q L_q^-1 on the extra rows of up to two factored systems, one launch (nk_trsm.hip)
 int launch_trsm_right_lower_pair(nk_ctx* ctx, const CholSys* sys, int nsys);
 

@@ -447,7 +447,11 @@ int cholesky_lower_pair_async(nk_ctx* ctx, const CholSys* sys, int nsys) {
       }
     }
     NK_TRY(launch_potrf_diag_pair(ctx, Ajj, lda, nbj, Li, nsys, jb));
-    NK_TRY(launch_gemm_pair(ctx, false, true, panel, nsys));
+    {
+      int rc_panel = NK_OK;  // 64 x 64 panel product: specialised kernel (nk_trail.hip), generic engine otherwise
+      if (!launch_chol_panel_pair(ctx, panel, nsys, &rc_panel)) NK_TRY(launch_gemm_pair(ctx, false, true, panel, nsys));
+      NK_TRY(rc_panel);
+    }
     {
       int rc_trail = NK_OK;  // K = 64 rank update: specialised kernel (nk_trail.hip), generic engine otherwise
       if (!launch_chol_trail_pair(ctx, trail, nsys, &rc_trail)) NK_TRY(launch_gemm_pair(ctx, false, true, trail, nsys));
@@ -517,7 +521,11 @@ int cholesky_aug_pair_async(nk_ctx* ctx, const CholSys* sys, int nsys, hipEvent_
       }
     }
     NK_TRY(launch_potrf_diag_pair(ctx, Ajj, lda, nbj, Li, nsys, jb));
-    NK_TRY(launch_gemm_pair(ctx, false, true, panel, nsys));
+    {
+      int rc_panel = NK_OK;  // 64 x 64 panel product: specialised kernel (nk_trail.hip), generic engine otherwise
+      if (!launch_chol_panel_pair(ctx, panel, nsys, &rc_panel)) NK_TRY(launch_gemm_pair(ctx, false, true, panel, nsys));
+      NK_TRY(rc_panel);
+    }
     {
       int rc_trail = NK_OK;  // K = 64 rank update: specialised kernel (nk_trail.hip), generic engine otherwise
       if (!launch_chol_trail_pair(ctx, trail, nsys, &rc_trail)) NK_TRY(launch_gemm_pair(ctx, false, true, trail, nsys));

@@ -124,4 +124,95 @@ bool launch_chol_trail_pair(nk_ctx* ctx, const GemmCall* calls, int ncalls, int*
   return true;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Panel product of the same step:  P <- P Linv_jj^T  (rows x 64 times 64 x 64, in place: a workgroup reads exactly the
+// 128 rows it writes, and only after all of them have been read).  Same register-only scheme as the trailing update.
+// ---------------------------------------------------------------------------------------------------------------
+struct PanelSys {
+  double* P;
+  int64_t ldp;
+  const double* Linv;  // 64 x 64, row-major, leading dimension 64
+  int rows;
+  int nblocks;
+};
+struct PanelBatch {
+  PanelSys s[2];
+};
+
+__global__ void __launch_bounds__(256) chol_panel_kernel(PanelBatch pb) {
+  const PanelSys s = pb.s[blockIdx.y];
+  if ((int)blockIdx.x >= s.nblocks) return;
+  __builtin_amdgcn_s_setprio(2);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int m0 = blockIdx.x * 128 + wave * 32;
+  d4 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
+  const double* pa[2];
+  const double* pl[4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) pa[i] = s.P + (int64_t)min(m0 + 16 * i + l15, s.rows - 1) * s.ldp + 8 * l4;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) pl[j] = s.Linv + (16 * j + l15) * 64 + 8 * l4;  // output column c <-> row c of Linv
+  double a[2][2][8], b[2][4][8];  // both halves of K are loaded before anything is stored (in-place update)
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[h][i][ks] = pa[i][32 * h + ks];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[h][j][ks] = pl[j][32 * h + ks];
+    }
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[h][i][ks], b[h][j][ks], acc[i][j], 0, 0, 0);
+  // every wave of the workgroup must have its raw rows in registers before any wave overwrites (waves own disjoint
+  // rows, so this is only needed against the clamped loads of the last, partial tile)
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int row = m0 + 16 * i + l4 + 4 * reg;
+        if (row < s.rows) s.P[(int64_t)row * s.ldp + 16 * j + l15] = acc[i][j][reg];
+      }
+}
+
+// panel products of up to two systems; calls[q] as prepared for the generic engine (C = A in place, B = Linv_jj with
+// leading dimension 64, N = K = 64, alpha = 1, beta = 0).  false: not that shape.
+bool launch_chol_panel_pair(nk_ctx* ctx, const GemmCall* calls, int ncalls, int* rc) {
+  *rc = NK_OK;
+  PanelBatch pb;
+  int maxblocks = 0;
+  for (int q = 0; q < 2; ++q) {
+    PanelSys& t = pb.s[q];
+    t = PanelSys{};
+    if (q >= ncalls || calls[q].M <= 0 || calls[q].N <= 0) continue;
+    const GemmCall& c = calls[q];
+    if (c.K != 64 || c.N != 64 || c.A != c.C || c.lda != c.ldc || c.ldb != 64 || c.alpha != 1.0 || c.beta != 0.0) return false;
+    t.P = c.C; t.ldp = c.ldc; t.Linv = c.B; t.rows = (int)c.M;
+    t.nblocks = (t.rows + 127) / 128;
+    if (t.nblocks > maxblocks) maxblocks = t.nblocks;
+  }
+  if (maxblocks == 0) return true;
+  hipLaunchKernelGGL(chol_panel_kernel, dim3((unsigned)maxblocks, 2), dim3(256), 0, ctx->stream, pb);
+  if (hipGetLastError() != hipSuccess) {
+    set_error("chol_panel launch failed");
+    *rc = NK_ERR_HIP;
+  }
+  return true;
+}
+
 }  // namespace nk
