@@ -793,13 +793,7 @@ static int fit_impl(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int6
   sys[1].P = G3; sys[1].ldp = m; sys[1].m = m; sys[1].Linv = Linv2; sys[1].extra = d;    // [inner_rec; left_rec]
   // both systems advance in lock step (paired launches); the per-block kernels are latency bound and leave the chip
   // mostly idle ...
-  // The square-root iteration (side stream) is held back until the chain has done its first `head` block steps: beside
-  // the GEMMs a chain step takes twice as long, and the iteration has slack at the end (it finishes before the chain).
-  // (C4: 42.7 ms per fit with a head of 4-6 steps against 42.9 without and 43.4 with 8)
-  const int chain_blocks = (mp + CHOL_NB - 1) / CHOL_NB;
-  const int head = 5;
-  const bool hold = chain_blocks >= 4 * head;
-  NK_TRY(cholesky_aug_pair_async(ctx, sys, 2, hold ? ev[12] : nullptr, head - 1));  // G2 <- cross inner^-1 (m x mp) ; G4 <- left_rec inner_rec^-1 (d x m)
+  NK_TRY(cholesky_aug_pair_async(ctx, sys, 2));  // G2 <- cross inner^-1 (m x mp) ; G4 <- left_rec inner_rec^-1 (d x m)
   tr.mark("cholesky + solves issued");
 
   // ---- ... while S = K_mm^{1/2}, S^{-1} (regressors.py:140,163) runs on the side stream (GEMM bound) --------------------
@@ -823,7 +817,6 @@ static int fit_impl(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int6
     SideScope side(ctx);
     NK_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_fork, 0));
     NK_HIP(hipStreamWaitEvent(ctx->stream, ev[9], 0));
-    if (hold) NK_HIP(hipStreamWaitEvent(ctx->stream, ev[12], 0));
     NK_HIP(hipEventRecord(ev[6], ctx->stream));
     NK_TRY(sqrtm_finish(ctx, &splan, mdl->S, mdl->Sinv));
     NK_HIP(hipEventRecord(ev[7], ctx->stream));
