@@ -269,6 +269,10 @@ struct TnSkip {
   const double* state = nullptr;
   int step = 0;
   const double* select = nullptr;
+  // single symmetric product C: the reduce kernel also leaves per-workgroup partial sums of (C - I)^2 here (at least
+  // 8 * tiles entries); *resid_count receives how many
+  double* resid_partials = nullptr;
+  int* resid_count = nullptr;
 };
 bool tn_fast_ok(const TnProblem& p);  // alignment / leading-dimension requirements of the LDS-DMA path
 int launch_gemm_tn_multi(nk_ctx* ctx, const TnProblem* probs, int nprob, int64_t K, int splitk /*0=auto*/,

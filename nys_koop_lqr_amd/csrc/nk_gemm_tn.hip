@@ -327,6 +327,9 @@ struct TnRedParams {
   const double* slab;
   const double* skip_state;  // see TnParams
   int skip_step;
+  // optional (single symmetric problem): every workgroup leaves sum (C - I)^2 over its band in resid_partials[block]
+  // (mirrored tiles counted twice), for a convergence check of ||C - I||_F without a separate pass over C
+  double* resid_partials;
 };
 
 // C = alpha * sum_s slab[tile][s] + beta * C (bounds, mirror, transposed copy).  RPARTS workgroups per tile, each summing
@@ -360,6 +363,7 @@ __global__ void __launch_bounds__(256) gemm_tn_reduce_kernel(TnRedParams P) {
   const bool mirror = pr.tri == TRI_UPPER_MIRROR && tm != tn;
   const bool transposed = mirror || pr.Ct != nullptr;
   const int row0 = tm * TBM + part * 16, col0 = tn * TBM;
+  double rsum = 0.0;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int idx = threadIdx.x * 2 + 512 * i;
@@ -374,8 +378,21 @@ __global__ void __launch_bounds__(256) gemm_tn_reduce_kernel(TnRedParams P) {
         if (pr.beta != 0.0) v += pr.beta * pr.C[(int64_t)row * pr.ldc + col];
         pr.C[(int64_t)row * pr.ldc + col] = v;
         if (pr.Caff) pr.Caff[(int64_t)row * pr.ldc + col] = pr.aff_a * v + (row == col ? pr.aff_c : 0.0);
+        const double e = v - (row == col ? 1.0 : 0.0);
+        rsum = fma(e, e, rsum);
       }
       if (transposed) sh[r][c + h] = v;
+    }
+  }
+  if (P.resid_partials != nullptr) {  // fixed-order workgroup sum (uniform branch)
+    __shared__ double wsum[4];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) rsum += __shfl_down(rsum, off, 64);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = rsum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const double w = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+      P.resid_partials[blockIdx.x] = mirror ? 2.0 * w : w;
     }
   }
   if (!transposed) return;
@@ -469,6 +486,7 @@ int launch_gemm_tn_multi(nk_ctx* ctx, const TnProblem* probs, int nprob, int64_t
     R.p[q].tile_begin = 1 << 30;
   }
   const int ktiles_total = (int)((K + TBK - 1) / TBK);
+  const bool want_resid = skip && skip->resid_partials != nullptr;
   if (splitk <= 0) {
     // Pick the number of K slices with a small cost model calibrated on MI355X (profiles/r01_*): a k-step costs
     // 1.22 units per workgroup when two workgroups share a CU and 2.35 when a workgroup is alone on its CU (one wave
@@ -492,6 +510,7 @@ int launch_gemm_tn_multi(nk_ctx* ctx, const TnProblem* probs, int nprob, int64_t
       if (t < best) { best = t; splitk = c; }
     }
   }
+  if (want_resid && splitk < 2) splitk = 2;  // the residual partials come out of the reduce kernel
   P.nprob = nprob; P.ntiles = ntiles; P.K = (int)K; P.splitk = splitk;
   P.klen = ((ktiles_total + splitk - 1) / splitk) * TBK;
   if (P.klen == 0) P.klen = TBK;
@@ -504,6 +523,8 @@ int launch_gemm_tn_multi(nk_ctx* ctx, const TnProblem* probs, int nprob, int64_t
   P.skip_state = R.skip_state = skip ? skip->state : nullptr;
   P.skip_step = R.skip_step = skip ? skip->step : 0;
   P.select_state = skip ? skip->select : nullptr;
+  R.resid_partials = (skip && splitk > 1 && nprob == 1) ? skip->resid_partials : nullptr;
+  if (skip && skip->resid_count) *skip->resid_count = R.resid_partials ? ntiles * RPARTS : 0;
   if (!g_tn_attr_set) {
     NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_f64_kernel<0>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES));

@@ -842,10 +842,15 @@ int sqrtm_finish(nk_ctx* ctx, SqrtPlan* plan, double* S, double* Sinv) {
     double* state = plan->d_sc + 5;
     NK_HIP(hipMemsetAsync(state, 0, 3 * sizeof(double), ctx->stream));
     double* rpart = nullptr;
-    NK_TRY(arena_alloc_t(ctx, (size_t)grid_for((int64_t)m * m, ctx->num_cu), &rpart));
+    {
+      const size_t mt = (size_t)(m + 127) / 128;
+      const size_t need = std::max((size_t)grid_for((int64_t)m * m, ctx->num_cu), mt * (mt + 1) / 2 * 8);
+      NK_TRY(arena_alloc_t(ctx, need, &rpart));
+    }
     for (int k = 0; k < kmax; ++k) {
       TnSkip skip;
       skip.state = state; skip.step = k;
+      int npart = 0;  // residual partials written by the reduce kernel of the M product (k > 0)
       if (k == 0) {
         NK_TRY(launch_transpose(ctx, plan->P, plan->ldp, M, m, m, m));
         NK_TRY(launch_axpby2d(ctx, 0.5 / c, plan->P, plan->ldp, 0.5 / c, M, m, m, m));
@@ -855,14 +860,18 @@ int sqrtm_finish(nk_ctx* ctx, SqrtPlan* plan, double* S, double* Sinv) {
         TnProblem pm;
         pm.A = X; pm.B = X; pm.C = M; pm.lda = pm.ldb = pm.ldc = m; pm.M = pm.N = m; pm.tri = TRI_UPPER_MIRROR;
         pm.Caff = T; pm.aff_a = -0.5 * s2k * sck; pm.aff_c = 1.5 * sck;
-        NK_TRY(launch_gemm_tn_multi(ctx, &pm, 1, m, 0, nullptr, true, &skip));
+        TnSkip skip_m = skip;
+        skip_m.resid_partials = rpart; skip_m.resid_count = &npart;
+        NK_TRY(launch_gemm_tn_multi(ctx, &pm, 1, m, 0, nullptr, true, &skip_m));
       }
       if (checks[k]) {
-        // residual partials (one launch), then their sum and the convergence flag (one launch)
-        const int blocks = grid_for((int64_t)m * m, ctx->num_cu);
-        hipLaunchKernelGGL(frob_mi_partial_kernel, dim3(blocks), dim3(256), 0, ctx->stream, M, (int64_t)m, m, rpart,
-                           skip.state, skip.step);
-        hipLaunchKernelGGL(ns_flag_kernel, dim3(1), dim3(256), 0, ctx->stream, rpart, blocks, m, k, state);
+        if (npart == 0) {  // M_0 (no product) or a single-slice product: separate pass over M for the partials
+          npart = grid_for((int64_t)m * m, ctx->num_cu);
+          hipLaunchKernelGGL(frob_mi_partial_kernel, dim3(npart), dim3(256), 0, ctx->stream, M, (int64_t)m, m, rpart,
+                             skip.state, skip.step);
+        }
+        // sum of the partials in index order and the convergence flag (one launch)
+        hipLaunchKernelGGL(ns_flag_kernel, dim3(1), dim3(256), 0, ctx->stream, rpart, npart, m, k, state);
         NK_HIP(hipGetLastError());
       }
       if (k == 0) {
