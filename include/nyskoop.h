@@ -26,13 +26,14 @@
 extern "C" {
 #endif
 
-#define NK_ABI_VERSION 1
+#define NK_ABI_VERSION 2
 
 enum {
   NK_OK = 0,
   NK_ERR_BAD_ARG = -1,        /* NULL / negative size / lengthscale-dimension mismatch (sklearn ValueError) */
   NK_ERR_HIP = -2,            /* a HIP runtime call failed */
-  NK_ERR_NOT_SPD = -3,        /* Cholesky met a non-positive pivot (reference: lstsq would truncate) */
+  NK_ERR_NOT_SPD = -3,        /* Cholesky met a non-positive pivot and strict mode is on (nk_set_strict_spd); by
+                                 default the solve falls back to gelsd's rank-truncated minimum-norm solution */
   NK_ERR_OOM = -4,            /* HBM allocation failed */
   NK_ERR_NO_CONVERGENCE = -5, /* matrix square-root iteration did not converge */
   NK_ERR_NO_DEVICE = -6       /* no gfx950 device visible */
@@ -66,6 +67,11 @@ typedef struct nk_fit_stats {
                                 square root is one quadratically convergent step beyond that iterate) */
   double gram_flops;         /* algorithmic flop of the Gram contractions actually issued */
   double kmat_pairs;         /* number of (row,row,dim) triples evaluated by the kernel-matrix builds */
+  /* numerical rank used for the two regularised systems (regressors.py:155,165): m+p and m when the Cholesky
+   * factorisations succeeded (full rank), otherwise the number of singular values kept by the pseudo-inverse path -- what
+   * scipy.linalg.lstsq (gelsd) reports as `rank` */
+  int32_t rank_inner;
+  int32_t rank_inner_rec;
 } nk_fit_stats;
 
 typedef struct nk_ctx nk_ctx;
@@ -85,6 +91,28 @@ void* nk_stream(nk_ctx* ctx);
  * -> sklearn -> cdist).  K(Z,Z), lift queries and nk_kernel_matrix always use direct differences.
  * Also settable with the environment variable NYSKOOP_KMAT=direct before nk_create. */
 int nk_set_kmat_mode(nk_ctx* ctx, int mode);
+/* Rank-deficient regularised systems.  scipy.linalg.lstsq (regressors.py:155,165; LAPACK gelsd, rcond = eps) silently
+ * returns the minimum-norm solution with singular values <= eps * sigma_max dropped.  By default (strict = 0) the library
+ * does the same -- a one-sided Jacobi SVD on the device with the same cut-off -- whenever its Cholesky factorisation meets
+ * a non-positive pivot or pivots that span more than 1/(order * eps) (1/(8 * order * eps) in nk_solve_spd), i.e. a matrix
+ * that is singular to working precision.  (A system whose Cholesky succeeds with healthy pivots is solved at full rank even if its singular values
+ * reach below eps * sigma_max: there gelsd's rank decision is taken inside its own rounding noise and no two solvers
+ * agree on it -- DESIGN.md section 3.)  strict = 1 turns the fallback into NK_ERR_NOT_SPD (also: environment variable
+ * NYSKOOP_STRICT_SPD=1 before nk_create). */
+int nk_set_strict_spd(nk_ctx* ctx, int strict);
+/* Stream ordering for DEVICE-pointer arguments: work already queued on `producer_stream` (a hipStream_t; NULL = the
+ * legacy default stream) is ordered before everything this context launches afterwards -- an event recorded on the
+ * producer stream that all of the context's streams wait for; the host does not block.  Call it before handing the
+ * library a device buffer that another stream is still writing (a torch tensor that is the output of a pending
+ * all-reduce, for example): the context's streams are non-blocking and do not synchronise with any other stream
+ * implicitly.  Results are complete when a call returns (every entry point synchronises its streams before returning
+ * unless documented otherwise), so no ordering is needed in the other direction. */
+int nk_wait_stream(nk_ctx* ctx, void* producer_stream);
+/* Releases everything the library still holds on every device -- live contexts (their streams, events and workspaces),
+ * live models, the model-buffer pool and page-locked host blocks -- after waiting for pending work.  Handles that were
+ * live become invalid; destroying them afterwards is a harmless no-op, so language bindings may call this from an
+ * exit hook that runs BEFORE the HIP runtime's own static destructors and keep their finalisers.  Idempotent. */
+int nk_shutdown(void);
 
 /* page-locked host memory for result arrays (device->host copies into it run at the PCIe rate and skip first-touch
  * page faults); nk_host_free(NULL) is a no-op. */
@@ -182,6 +210,15 @@ int nk_rollout(nk_ctx* ctx, const nk_model* model, const double* x0, int64_t ldx
  *   K: p x m gain; phi0, phi_ref: m-vectors; out_x: steps x d visited states C phi_t; out_u: steps x p. ---- */
 int nk_closed_loop(nk_ctx* ctx, const nk_model* model, const double* K, const double* phi0,
                    const double* phi_ref, int32_t steps, double* out_x, double* out_u);
+/* the same for `batch` independent loops that share the gain: phi0, phi_ref: batch x m; out_x: batch x steps x d;
+ * out_u: batch x steps x p (multi-seed / multi-reference sweeps of benchmark_lqr_cloth.py:212-270). */
+int nk_closed_loop_batch(nk_ctx* ctx, const nk_model* model, const double* K, const double* phi0,
+                         const double* phi_ref, int32_t steps, int32_t batch, double* out_x, double* out_u);
+/* ---- rollout of explicit operators without a model (any estimator that exposes A, B, C: the exact-kernel comparator of
+ *   benchmark_lqr_hjb.py:334-381, un-pickled gains): z0: batch x m lifted initial states; A: m x m, B: m x p, C: d x m
+ *   (row-major, host or device); U, out_x, out_z as in nk_rollout. --------------------------------------------------- */
+int nk_linear_rollout(nk_ctx* ctx, const double* A, const double* B, const double* C, int32_t m, int32_t d, int32_t p,
+                      const double* z0, const double* U, int32_t T, int32_t batch, double* out_x, double* out_z);
 
 /* ---- building blocks exported for parity tests and reuse (device or host pointers) --------------------- */
 /* C[M x N] = alpha * op(A) op(B) + beta * C;  transA: A is stored K x M;  transB: B is stored N x K. */
@@ -190,7 +227,8 @@ int nk_gemm(nk_ctx* ctx, int transA, int transB, int64_t M, int64_t N, int64_t K
 /* S = P^{1/2}, Sinv = P^{-1/2} for symmetric positive definite P (m x m); regressors.py:140,163,175. */
 int nk_sqrtm_spd(nk_ctx* ctx, const double* P, int64_t ldp, int32_t m, double* S, double* Sinv,
                  int32_t* iters, double* residual);
-/* X = P^{-1} R for symmetric positive definite P (m x m), R: m x nrhs; regressors.py:155,165. */
+/* X = P^{-1} R for symmetric positive definite P (m x m), R: m x nrhs; regressors.py:155,165.  A numerically singular P
+ * gets lstsq's minimum-norm solution (see nk_set_strict_spd). */
 int nk_solve_spd(nk_ctx* ctx, const double* P, int64_t ldp, int32_t m, const double* R, int64_t ldr,
                  int32_t nrhs, double* X, int64_t ldxo);
 

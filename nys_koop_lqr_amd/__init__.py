@@ -4,10 +4,10 @@ libnyskoop.so (include/nyskoop.h) with ctypes.  There is no CPU fallback: import
 compute call without the built library and a gfx950 device raises.
 """
 from .kernels import KernelWrapper, LinearKernelWrapper, ThreeDimensionalKernel  # noqa: F401
-from .regressors import KoopmanKernelRegressor, KoopmanNystromRegressor, KoopmanRegressor  # noqa: F401
-from ._lib import NyskoopError, get_context, library_path  # noqa: F401
+from .regressors import KoopmanKernelRegressor, KoopmanNystromRegressor, KoopmanRegressor, linear_rollout  # noqa: F401
+from ._lib import NyskoopError, get_context, library_path, shutdown  # noqa: F401
 
 __all__ = [
     "KoopmanRegressor", "KoopmanNystromRegressor", "KoopmanKernelRegressor", "ThreeDimensionalKernel", "KernelWrapper",
-    "LinearKernelWrapper", "NyskoopError", "get_context", "library_path",
+    "LinearKernelWrapper", "NyskoopError", "get_context", "library_path", "linear_rollout", "shutdown",
 ]

@@ -1,4 +1,5 @@
 """ctypes binding of libnyskoop.so (include/nyskoop.h).  Fails loudly: no library or no GPU => exception."""
+import atexit
 import ctypes as C
 import os
 import sys
@@ -30,7 +31,7 @@ class FitStats(C.Structure):
                 ("ms_gram", C.c_double), ("ms_sqrt", C.c_double), ("ms_solve", C.c_double),
                 ("ms_gram_kernel_avg", C.c_double), ("gram_kernel_launches", C.c_int32),
                 ("sqrt_iters", C.c_int32), ("sqrt_residual", C.c_double), ("gram_flops", C.c_double),
-                ("kmat_pairs", C.c_double)]
+                ("kmat_pairs", C.c_double), ("rank_inner", C.c_int32), ("rank_inner_rec", C.c_int32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -51,6 +52,9 @@ SIGNATURES = {
     "nk_synchronize": (C.c_int, [_P]),
     "nk_stream": (_P, [_P]),
     "nk_set_kmat_mode": (C.c_int, [_P, C.c_int]),
+    "nk_set_strict_spd": (C.c_int, [_P, C.c_int]),
+    "nk_wait_stream": (C.c_int, [_P, _P]),
+    "nk_shutdown": (C.c_int, []),
     "nk_host_alloc": (_P, [C.c_uint64]),
     "nk_host_free": (None, [_P]),
     "nk_kernel_matrix": (C.c_int, [_P, C.POINTER(KernelDesc), _P, _I64, _I64, _P, _I64, _I64, _P, _I64]),
@@ -75,6 +79,8 @@ SIGNATURES = {
     "nk_score_neg_rmse": (C.c_int, [_P, _P, _P, _I64, _P, _I64, _I64, C.POINTER(_D)]),
     "nk_rollout": (C.c_int, [_P, _P, _P, _I64, _P, _I32, _I32, _P, _P]),
     "nk_closed_loop": (C.c_int, [_P, _P, _P, _P, _P, _I32, _P, _P]),
+    "nk_closed_loop_batch": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _P, _P]),
+    "nk_linear_rollout": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _P, _P, _I32, _I32, _P, _P]),
     "nk_gemm": (C.c_int, [_P, C.c_int, C.c_int, _I64, _I64, _I64, _D, _P, _I64, _P, _I64, _D, _P, _I64]),
     "nk_sqrtm_spd": (C.c_int, [_P, _P, _I64, _I32, _P, _P, C.POINTER(_I32), C.POINTER(_D)]),
     "nk_solve_spd": (C.c_int, [_P, _P, _I64, _I32, _P, _I64, _I32, _P, _I64]),
@@ -112,7 +118,29 @@ def load_library():
                 fn.restype = res
                 fn.argtypes = args
             _lib = lib
+            # Deterministic teardown: release every stream, event, workspace, model buffer and page-locked block while
+            # the HIP runtime (and a profiler's tool library, if one is attached) is still fully alive.  atexit hooks of
+            # the interpreter run before Py_Finalize and before the C runtime's exit handlers / static destructors;
+            # afterwards the finalisers of Context / regressor / pinned-array objects find their handles already
+            # released (nk_destroy, nk_model_destroy and nk_host_free are no-ops for handles the library no longer knows).
+            atexit.register(shutdown)
     return _lib
+
+
+def shutdown():
+    """nk_shutdown(): wait for pending work and release everything the library holds.  Idempotent; contexts, device
+    models and pinned result arrays that are still referenced become invalid (operators already fetched stay valid only
+    if they were copied: `np.array(reg.A)`)."""
+    lib = _lib
+    if lib is None:
+        return
+    with _pools_lock:
+        pools = list(_pools.values())
+        _pools.clear()
+    for pool in pools:  # worker threads hold contexts in thread-local storage; stop them before their streams go away
+        pool.shutdown(wait=True)
+    _PinnedBlock.drain()
+    lib.nk_shutdown()
 
 
 def check(rc):
@@ -177,6 +205,24 @@ class Context:
     def stream(self):
         return self.lib.nk_stream(self.handle)
 
+    def set_strict_spd(self, strict):
+        """True: a numerically rank-deficient regularised system raises LinAlgError (NK_ERR_NOT_SPD) instead of being
+        solved like scipy.linalg.lstsq does (minimum-norm solution, singular values <= eps * sigma_max dropped)."""
+        check(self.lib.nk_set_strict_spd(self.handle, 1 if strict else 0))
+
+    def wait_for(self, *objs):
+        """Order the context's streams after the work queued on torch's current stream whenever one of `objs` is a
+        device tensor: the library's streams are non-blocking, so nothing else makes them wait for, say, a pending
+        all-reduce that produces the tensor (nk_wait_stream; the host does not block)."""
+        torch = sys.modules.get("torch")
+        if torch is None:
+            return
+        for o in objs:
+            if hasattr(o, "data_ptr") and hasattr(o, "stride") and getattr(o, "is_cuda", False):
+                stream = torch.cuda.current_stream(o.device)
+                check(self.lib.nk_wait_stream(self.handle, C.c_void_p(stream.cuda_stream)))
+                return
+
     def set_kmat_mode(self, mode):
         """0 = automatic (Gram form on the MFMA engine for d >= 32), 1 = always direct differences."""
         check(self.lib.nk_set_kmat_mode(self.handle, int(mode)))
@@ -185,26 +231,42 @@ class Context:
 class _PinnedBlock:
     """A page-locked host block that returns to a small pool when its last array view dies."""
     _pool = {}
+    _lock = threading.Lock()
+    _closed = False
 
     def __init__(self, nbytes):
         self.nbytes = int(nbytes)
-        free = _PinnedBlock._pool.get(self.nbytes)
-        if free:
-            self.ptr = free.pop()
-        else:
+        self.ptr = None
+        with _PinnedBlock._lock:
+            free = _PinnedBlock._pool.get(self.nbytes)
+            if free:
+                self.ptr = free.pop()
+        if self.ptr is None:
             self.ptr = load_library().nk_host_alloc(self.nbytes)
             if not self.ptr:
                 raise MemoryError(f"nk_host_alloc({self.nbytes}) failed")
 
     def __del__(self):
         try:
-            free = _PinnedBlock._pool.setdefault(self.nbytes, [])
-            if len(free) < 8:
-                free.append(self.ptr)
-            else:
-                load_library().nk_host_free(self.ptr)
+            with _PinnedBlock._lock:
+                free = _PinnedBlock._pool.setdefault(self.nbytes, [])
+                if not _PinnedBlock._closed and len(free) < 8:
+                    free.append(self.ptr)
+                    return
+            load_library().nk_host_free(self.ptr)  # a no-op after nk_shutdown
         except Exception:
             pass
+
+    @classmethod
+    def drain(cls):
+        """Free the pooled blocks and stop pooling (blocks still referenced by arrays are released by nk_shutdown)."""
+        with cls._lock:
+            ptrs = [p for free in cls._pool.values() for p in free]
+            cls._pool.clear()
+            cls._closed = True
+        lib = load_library()
+        for p in ptrs:
+            lib.nk_host_free(p)
 
 
 def pinned_empty(shape):

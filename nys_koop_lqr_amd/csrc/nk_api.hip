@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <algorithm>
 #include <mutex>
+#include <set>
 
 namespace nk {
 
@@ -212,8 +213,15 @@ struct ModelBuf {
   size_t bytes;
   double* ptr;
 };
+// Everything the library owns is registered here, so that nk_shutdown can release it in a defined order BEFORE the HIP
+// runtime's static destructors run, and so that destroying a handle twice (or after nk_shutdown) is a no-op.
 static std::mutex g_pool_mu;
 static std::vector<ModelBuf> g_pool;
+static std::mutex g_reg_mu;
+static std::set<nk_ctx*> g_ctxs;
+static std::set<nk_model*> g_models;
+static std::set<void*> g_host_blocks;
+
 static double* pool_take(int device, size_t bytes) {
   std::lock_guard<std::mutex> lk(g_pool_mu);
   for (size_t i = 0; i < g_pool.size(); ++i)
@@ -235,6 +243,14 @@ static void pool_give(int device, size_t bytes, double* ptr) {
   (void)hipSetDevice(device);
   (void)hipFree(ptr);
 }
+static void pool_drain() {
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  for (auto& b : g_pool) {
+    (void)hipSetDevice(b.device);
+    (void)hipFree(b.ptr);
+  }
+  g_pool.clear();
+}
 
 static int model_alloc(nk_ctx* ctx, int m, int d, int p, nk_model** out) {
   nk_model* mdl = new nk_model();
@@ -250,7 +266,7 @@ static int model_alloc(nk_ctx* ctx, int m, int d, int p, nk_model** out) {
     if (e != hipSuccess) {
       (void)hipGetLastError();
       delete mdl;
-      set_error("model allocation failed: %s", hipGetErrorString(e));
+      set_error("model allocation of %zu bytes failed: %s", total * sizeof(double), hipGetErrorString(e));
       return NK_ERR_OOM;
     }
   }
@@ -264,6 +280,10 @@ static int model_alloc(nk_ctx* ctx, int m, int d, int p, nk_model** out) {
   mdl->Sinv = take((size_t)m * m);
   mdl->Z = take((size_t)m * d);
   mdl->winv = take((size_t)d);
+  {
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    g_models.insert(mdl);
+  }
   *out = mdl;
   return NK_OK;
 }
@@ -383,18 +403,26 @@ int nk_create(int device, nk_ctx** out) {
   NK_HIP(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
   NK_HIP(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
   NK_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->d_info), 256));
+  ctx->d_piv = reinterpret_cast<unsigned long long*>(ctx->d_info + 16);  // 8 x 8 bytes behind the 4 flag slots
   NK_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->d_scalars), 64 * sizeof(double)));
   NK_HIP(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_scalars), 64 * sizeof(double)));
-  NK_HIP(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_info), 64));
+  NK_HIP(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_info), 256));
+  ctx->h_piv = reinterpret_cast<unsigned long long*>(ctx->h_info + 16);
   for (int i = 0; i < 16; ++i) NK_HIP(hipEventCreate(&ctx->ev[i]));
+  NK_HIP(hipEventCreateWithFlags(&ctx->ev_ext, hipEventDisableTiming));
   const char* km = getenv("NYSKOOP_KMAT");
   ctx->kmat_mode = (km && strcmp(km, "direct") == 0) ? 1 : 0;
+  const char* st = getenv("NYSKOOP_STRICT_SPD");
+  ctx->strict_spd = (st && atoi(st) != 0) ? 1 : 0;
+  {
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    g_ctxs.insert(ctx);
+  }
   *out = ctx;
   return NK_OK;
 }
 
-int nk_destroy(nk_ctx* ctx) {
-  if (!ctx) return NK_OK;
+static void destroy_ctx_unregistered(nk_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream_main);
   (void)hipStreamSynchronize(ctx->stream_side);
@@ -404,17 +432,81 @@ int nk_destroy(nk_ctx* ctx) {
   for (auto& c : ctx->arena_side.chunks) (void)hipFree(c.base);
   (void)hipEventDestroy(ctx->ev_fork);
   (void)hipEventDestroy(ctx->ev_join);
+  if (ctx->ev_ext) (void)hipEventDestroy(ctx->ev_ext);
   (void)hipStreamDestroy(ctx->stream_side);
   (void)hipStreamDestroy(ctx->stream_prep);
   (void)hipStreamDestroy(ctx->stream_copy);
   (void)hipFree(ctx->d_info);
   (void)hipFree(ctx->d_scalars);
   if (ctx->d_zeros) (void)hipFree(ctx->d_zeros);
+  if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
   (void)hipHostFree(ctx->h_scalars);
   (void)hipHostFree(ctx->h_info);
   for (int i = 0; i < 16; ++i) (void)hipEventDestroy(ctx->ev[i]);
   (void)hipStreamDestroy(ctx->stream_main);
   delete ctx;
+}
+
+int nk_destroy(nk_ctx* ctx) {
+  if (!ctx) return NK_OK;
+  {
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    if (g_ctxs.erase(ctx) == 0) return NK_OK;  // already destroyed (nk_shutdown, or a second call)
+  }
+  destroy_ctx_unregistered(ctx);
+  return NK_OK;
+}
+
+static int model_wait_unchecked(nk_model* mdl);
+static void destroy_model_unregistered(nk_model* model, bool to_pool) {
+  (void)model_wait_unchecked(model);  // a pending asynchronous fetch still reads the buffers
+  if (to_pool) {
+    pool_give(model->device, model->bytes, model->buf);
+  } else {
+    (void)hipSetDevice(model->device);
+    (void)hipFree(model->buf);
+  }
+  delete model;
+}
+
+int nk_shutdown(void) {
+  std::set<nk_ctx*> ctxs;
+  std::set<nk_model*> models;
+  std::set<void*> blocks;
+  {
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    ctxs.swap(g_ctxs);
+    models.swap(g_models);
+    blocks.swap(g_host_blocks);
+  }
+  for (nk_ctx* c : ctxs) {  // drain everything first: models and pinned blocks may still be targets of queued copies
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream_main);
+    (void)hipStreamSynchronize(c->stream_side);
+    (void)hipStreamSynchronize(c->stream_prep);
+    (void)hipStreamSynchronize(c->stream_copy);
+  }
+  for (nk_model* m : models) destroy_model_unregistered(m, false);
+  for (nk_ctx* c : ctxs) destroy_ctx_unregistered(c);
+  pool_drain();
+  for (void* b : blocks) (void)hipHostFree(b);
+  return NK_OK;
+}
+
+int nk_set_strict_spd(nk_ctx* ctx, int strict) {
+  NK_REQUIRE(ctx != nullptr, "nk_set_strict_spd: null context");
+  ctx->strict_spd = strict ? 1 : 0;
+  return NK_OK;
+}
+
+int nk_wait_stream(nk_ctx* ctx, void* producer_stream) {
+  NK_REQUIRE(ctx != nullptr, "nk_wait_stream: null context");
+  NK_HIP(hipSetDevice(ctx->device));
+  NK_HIP(hipEventRecord(ctx->ev_ext, reinterpret_cast<hipStream_t>(producer_stream)));
+  NK_HIP(hipStreamWaitEvent(ctx->stream_main, ctx->ev_ext, 0));
+  NK_HIP(hipStreamWaitEvent(ctx->stream_side, ctx->ev_ext, 0));
+  NK_HIP(hipStreamWaitEvent(ctx->stream_prep, ctx->ev_ext, 0));
+  NK_HIP(hipStreamWaitEvent(ctx->stream_copy, ctx->ev_ext, 0));
   return NK_OK;
 }
 
@@ -433,11 +525,18 @@ void* nk_host_alloc(uint64_t bytes) {
     set_error("hipHostMalloc of %llu bytes failed", (unsigned long long)bytes);
     return nullptr;
   }
+  std::lock_guard<std::mutex> lk(g_reg_mu);
+  g_host_blocks.insert(p);
   return p;
 }
 
 void nk_host_free(void* ptr) {
-  if (ptr) (void)hipHostFree(ptr);
+  if (!ptr) return;
+  {
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    if (g_host_blocks.erase(ptr) == 0) return;  // not ours, or already released by nk_shutdown
+  }
+  (void)hipHostFree(ptr);
 }
 
 int nk_set_kmat_mode(nk_ctx* ctx, int mode) {
@@ -777,6 +876,12 @@ static int fit_impl(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int6
   NK_TRY(launch_axpby2d(ctx, gamma_n, Kj_in, m, 1.0, G1, mp, m, m));               // inner = G1 + gamma_n*blkdiag(K, I)
   if (p > 0) NK_TRY(launch_add_diag(ctx, G1 + (int64_t)m * mp + m, mp, p, gamma_n));
   NK_TRY(launch_axpby2d(ctx, gamma_n, Kj, m, 1.0, G3, m, m, m));                   // inner_rec = gamma_n K + G3
+  // The factorisations below work in place.  A copy of the assembled systems and their right-hand sides (one device
+  // copy of the packed block: 0.1 % of a fit) is what the rank-truncating fallback starts from if a pivot turns out
+  // non-positive (regressors.py:155,165: lstsq / gelsd semantics).
+  double* Gsave = nullptr;
+  NK_TRY(arena_alloc_t(ctx, gram_doubles(m, d, p), &Gsave));
+  NK_HIP(hipMemcpyAsync(Gsave, G1, gram_doubles(m, d, p) * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
   double *Linv = nullptr, *Linv2 = nullptr, *Sinvt = nullptr, *V1 = nullptr, *T1t = nullptr, *X1 = nullptr, *Wc = nullptr,
          *Ct = nullptr;
   const int nblk = (mp + CHOL_NB - 1) / CHOL_NB;
@@ -848,8 +953,36 @@ static int fit_impl(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int6
   NK_TRY(operator_products());
   NK_HIP(hipEventRecord(ev[5], ctx->stream));
   tr.mark("solve issued");
-  NK_TRY(cholesky_check_pair(ctx, sys, 2));  // synchronises the main stream (which has joined the side stream)
+  int chol_failed[2] = {0, 0};
+  NK_TRY(cholesky_fail_flags(ctx, sys, 2, chol_failed, 1.0));  // synchronises the main stream (which has joined the side stream)
   tr.mark("final sync");
+  int rank_sys[2] = {mp, m};
+  bool redo_products = false;
+  if (chol_failed[0] || chol_failed[1]) {
+    if (ctx->strict_spd) {  // NK_ERR_NOT_SPD
+      set_error("Cholesky: system %d is numerically rank deficient (non-positive or rounding-level pivot; the reference's "
+                "lstsq truncates here) and strict mode is on", chol_failed[0] ? 0 : 1);
+      return NK_ERR_NOT_SPD;
+    }
+    // numerically rank-deficient system(s): lstsq's (gelsd's) minimum-norm solution, singular values <= eps * sigma_max
+    // dropped (nk_pinv.hip)
+    const double rcond = 2.220446049250313e-16;
+    for (int q = 0; q < 2; ++q) {
+      if (!chol_failed[q]) continue;
+      PinvInfo pi;
+      if (q == 0)  // cross inner^+  ->  G2
+        NK_TRY(pinv_right_divide(ctx, Gsave, mp, mp, Gsave + (size_t)mp * mp, mp, m, G2, mp, rcond, &pi));
+      else         // left_rec inner_rec^+  ->  G4
+        NK_TRY(pinv_right_divide(ctx, Gsave + gram_block1(m, p), m, m, Gsave + gram_block1(m, p) + (size_t)m * m, m, d, G4,
+                                 m, rcond, &pi));
+      if (!pi.converged) {
+        set_error("rank-revealing fallback: Jacobi SVD of system %d did not converge in %d sweeps", q, pi.sweeps);
+        return NK_ERR_NO_CONVERGENCE;
+      }
+      rank_sys[q] = pi.rank;
+    }
+    redo_products = true;
+  }
   {
     const int vr = sqrtm_verdict(ctx, &splan, &it, &resid);  // the iteration was queued without host round trips
     if (vr == NK_SQRT_RETRY) {
@@ -857,11 +990,14 @@ static int fit_impl(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int6
       // coupled iteration needs no factorisation; then everything that depends on the square root once more
       NK_TRY(sqrtm_spd_coupled(ctx, Kj, m, m, mdl->S, mdl->Sinv, &it, &resid));
       NK_TRY(sqrt_products());
-      NK_TRY(operator_products());
-      NK_HIP(hipStreamSynchronize(ctx->stream));
+      redo_products = true;
     } else {
       NK_TRY(vr);
     }
+  }
+  if (redo_products) {
+    NK_TRY(operator_products());
+    NK_HIP(hipStreamSynchronize(ctx->stream));
   }
   mdl->has_ops = true;
 
@@ -886,6 +1022,8 @@ static int fit_impl(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int6
     stats->gram_flops = 2.0 * ne * t128 * t128 * (tmp_ * (tmp_ + 1) / 2 + tm_ * tmp_ + tm_ * (tm_ + 1) / 2) +
                         2.0 * ne * (double)d * m;
     stats->kmat_pairs = 2.0 * ne * m * d + (same_centers ? 1.0 : 3.0) * (double)m * m * d;
+    stats->rank_inner = rank_sys[0];
+    stats->rank_inner_rec = rank_sys[1];
   }
   tr.mark("stats");
   if (ctx->arena.chunks.size() > 1 || ctx->arena_side.chunks.size() > 1) NK_TRY(arena_reset(ctx));  // coalesce now (everything is synchronised), not in the next call
@@ -972,9 +1110,11 @@ int nk_model_create(nk_ctx* ctx, const nk_kernel_desc* kd, const double* Zout, i
 
 int nk_model_destroy(nk_model* model) {
   if (!model) return NK_OK;
-  (void)nk_model_wait(model);  // a pending asynchronous fetch still reads the buffers
-  pool_give(model->device, model->bytes, model->buf);
-  delete model;
+  {
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    if (g_models.erase(model) == 0) return NK_OK;  // already destroyed (nk_shutdown, or a second call)
+  }
+  destroy_model_unregistered(model, true);
   return NK_OK;
 }
 
@@ -1074,8 +1214,18 @@ int nk_model_get_ops_async(nk_ctx* ctx, nk_model* mdl, double* G, int64_t ldg, d
   return NK_OK;
 }
 
+static int model_wait_unchecked(nk_model* mdl);
+
 int nk_model_wait(nk_model* mdl) {
   NK_REQUIRE(mdl != nullptr, "nk_model_wait: null model");
+  {
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    if (g_models.count(mdl) == 0) return NK_OK;  // released by nk_shutdown (which waited for the fetch itself)
+  }
+  return model_wait_unchecked(mdl);
+}
+
+static int model_wait_unchecked(nk_model* mdl) {
   if (mdl->ev_fetch) {
     hipError_t e = hipEventSynchronize(mdl->ev_fetch);
     (void)hipEventDestroy(mdl->ev_fetch);
@@ -1144,6 +1294,149 @@ int nk_score_neg_rmse(nk_ctx* ctx, const nk_model* mdl, const double* Xaug, int6
   return NK_OK;
 }
 
+// ---- small-call staging: the latency-bound entry points (rollouts, closed loops) read their host inputs from, and write
+//      their host outputs into, one page-locked block that the GPU addresses directly -- no DMA descriptors, no staging
+//      copies on the stream; the host moves the bytes with memcpy before the launch and after the one synchronisation.
+struct SmallStage {
+  nk_ctx* ctx = nullptr;
+  size_t off = 0;
+  struct Out { double* stage; double* user; int64_t user_ld; int64_t rows, cols; };
+  std::vector<Out> outs;
+};
+constexpr size_t SMALL_STAGE_LIMIT = (size_t)4 << 20;
+static int small_reserve(nk_ctx* ctx, size_t bytes) {
+  if (ctx->h_stage_bytes >= bytes) return NK_OK;
+  if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+  ctx->h_stage = nullptr;
+  ctx->h_stage_bytes = 0;
+  NK_HIP(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_stage), bytes, hipHostMallocDefault));
+  ctx->h_stage_bytes = bytes;
+  return NK_OK;
+}
+static const double* small_in(SmallStage& st, const double* host, int64_t ld, int64_t rows, int64_t cols) {
+  double* dst = reinterpret_cast<double*>(reinterpret_cast<char*>(st.ctx->h_stage) + st.off);
+  for (int64_t r = 0; r < rows; ++r) memcpy(dst + r * cols, host + r * ld, (size_t)cols * 8);
+  st.off += (((size_t)rows * cols * 8) + 255) & ~(size_t)255;
+  return dst;
+}
+static double* small_out(SmallStage& st, double* user, int64_t user_ld, int64_t rows, int64_t cols) {
+  double* dst = reinterpret_cast<double*>(reinterpret_cast<char*>(st.ctx->h_stage) + st.off);
+  st.off += (((size_t)rows * cols * 8) + 255) & ~(size_t)255;
+  st.outs.push_back(SmallStage::Out{dst, user, user_ld, rows, cols});
+  return dst;
+}
+static void small_finish(SmallStage& st) {  // after the stream has been synchronised
+  for (auto& o : st.outs)
+    for (int64_t r = 0; r < o.rows; ++r) memcpy(o.user + r * o.user_ld, o.stage + r * o.cols, (size_t)o.cols * 8);
+}
+static inline size_t pad256(size_t doubles) { return ((doubles * 8) + 255) & ~(size_t)255; }
+
+// z_{t+1} = G [z_t; u_t] (+ bias) for t < T-1 on Zall ([b][t][m], row 0 of every trajectory already holds z_0 unless
+// `chain.lift`), then x = C z for every (b, t).  One launch for the recursion when G fits in LDS, a matrix-vector /
+// GEMM launch per step otherwise.
+static int rollout_steps(nk_ctx* ctx, ChainArgs chain, bool z0_in_place) {
+  const int m = chain.m, p = chain.pu, T = chain.T, batch = chain.batch;
+  if (lifted_chain_ok(m, p, chain.lift ? chain.d : 0)) return launch_lifted_chain(ctx, chain);
+  NK_REQUIRE(!chain.lift && z0_in_place, "rollout_steps: internal: the stepwise path needs z_0 in place");
+  double* Zall = chain.Zall;
+  const int64_t ldz = chain.z_stride;
+  for (int t = 0; t + 1 < T; ++t) {
+    if (batch <= 16) {  // matrix-vector chain: one wave per row of G, trajectories in groups of 8
+      for (int b0 = 0; b0 < batch; b0 += 8) {
+        const int nb = batch - b0 < 8 ? batch - b0 : 8;
+        // the kernel takes one bias vector: trajectories with their own bias go one by one
+        if (chain.bias && chain.bias_stride != 0) {
+          for (int b = b0; b < b0 + nb; ++b)
+            NK_TRY(launch_lifted_step(ctx, chain.G, chain.ldg, m, m, p, Zall + (int64_t)b * ldz + (int64_t)t * m, ldz,
+                                      p > 0 ? chain.U + (int64_t)b * chain.u_stride + (int64_t)t * p : nullptr,
+                                      chain.u_stride, chain.bias + (int64_t)b * chain.bias_stride,
+                                      Zall + (int64_t)b * ldz + (int64_t)(t + 1) * m, ldz, 1));
+        } else {
+          NK_TRY(launch_lifted_step(ctx, chain.G, chain.ldg, m, m, p, Zall + (int64_t)b0 * ldz + (int64_t)t * m, ldz,
+                                    p > 0 ? chain.U + (int64_t)b0 * chain.u_stride + (int64_t)t * p : nullptr,
+                                    chain.u_stride, chain.bias, Zall + (int64_t)b0 * ldz + (int64_t)(t + 1) * m, ldz, nb));
+        }
+      }
+    } else {
+      double* zn = Zall + (int64_t)(t + 1) * m;
+      double beta = 0.0;
+      if (chain.bias) {  // z' = bias + ...
+        NK_TRY(launch_copy2d(ctx, chain.bias, chain.bias_stride, zn, ldz, batch, m));
+        beta = 1.0;
+      }
+      NK_TRY(launch_gemm(ctx, false, true, batch, m, m, 1.0, Zall + (int64_t)t * m, ldz, chain.G, chain.ldg, beta, zn, ldz));
+      if (p > 0)
+        NK_TRY(launch_gemm(ctx, false, true, batch, m, p, 1.0, chain.U + (int64_t)t * p, chain.u_stride, chain.G + m,
+                           chain.ldg, 1.0, zn, ldz));
+    }
+  }
+  return NK_OK;
+}
+
+static int rollout_impl(nk_ctx* ctx, const nk_model* mdl, const double* G, int64_t ldg, const double* Cop, int64_t ldc,
+                        int m, int d, int p, const double* x0, int64_t ldx0, const double* z0, const double* U, int32_t T,
+                        int32_t batch, double* out_x, double* out_z) {
+  // x0 != nullptr: lift through the model; otherwise z0 (batch x m) holds the lifted initial states
+  const int64_t nin = x0 ? d : m;
+  const double* first = x0 ? x0 : z0;
+  const bool have_u = p > 0 && T > 1;
+  const size_t need = pad256((size_t)batch * nin) + (have_u ? pad256((size_t)batch * T * p) : 0) +
+                      pad256((size_t)batch * T * d) + (out_z ? pad256((size_t)batch * T * m) : 0);
+  const bool small = need <= SMALL_STAGE_LIMIT && !is_device_ptr(first) && !(have_u && is_device_ptr(U)) &&
+                     !is_device_ptr(out_x) && !(out_z && is_device_ptr(out_z));
+  double* Zall = nullptr;  // [batch][T][m]
+  NK_TRY(arena_alloc_t(ctx, (size_t)batch * T * m, &Zall));
+  const int64_t ldz = (int64_t)T * m;
+  ChainArgs ch;
+  ch.G = G; ch.ldg = ldg; ch.m = m; ch.pu = p; ch.T = T; ch.batch = batch; ch.Zall = Zall; ch.z_stride = ldz;
+  ch.u_stride = (int64_t)T * p;
+  SmallStage st;
+  st.ctx = ctx;
+  MatIn xin, uin;
+  MatOut ox, oz;
+  double *xdev = nullptr, *zdev = nullptr;
+  if (small) {
+    NK_TRY(small_reserve(ctx, need));
+    xin.ptr = small_in(st, first, x0 ? ldx0 : m, batch, nin);
+    xin.ld = nin;
+    if (have_u) { uin.ptr = small_in(st, U, (int64_t)T * p, batch, (int64_t)T * p); uin.ld = (int64_t)T * p; }
+    xdev = small_out(st, out_x, d, (int64_t)batch * T, d);
+    if (out_z) zdev = small_out(st, out_z, m, (int64_t)batch * T, m);
+  } else {
+    NK_TRY(stage_in(ctx, first, x0 ? ldx0 : m, batch, nin, &xin));
+    if (have_u) NK_TRY(stage_in(ctx, U, (int64_t)T * p, batch, (int64_t)T * p, &uin));
+    NK_TRY(stage_out(ctx, out_x, d, (int64_t)batch * T, d, &ox));
+    xdev = ox.dev;
+    if (out_z) { NK_TRY(stage_out(ctx, out_z, m, (int64_t)batch * T, m, &oz)); zdev = oz.dev; }
+  }
+  ch.U = have_u ? uin.ptr : nullptr;
+  if (!have_u) ch.pu = (T > 1) ? p : 0;
+  const int64_t ldxo = small ? d : ox.ld, ldzo = small ? m : (out_z ? oz.ld : m);
+  bool z0_in_place = false;
+  if (x0 && lifted_chain_ok(m, ch.pu, d)) {  // the lift is done by the chain kernel itself
+    ch.lift = true; ch.x0 = xin.ptr; ch.x0_stride = xin.ld; ch.Zl = mdl->Z; ch.d = d; ch.winv = mdl->winv;
+    ch.Sinv = mdl->Sinv; ch.ktype = mdl->ktype; ch.sigma0 = mdl->sigma0;
+  } else if (x0) {
+    NK_TRY(lift_device(ctx, mdl, xin.ptr, xin.ld, batch, Zall, ldz));  // z_0 = phi(x_0) for every trajectory
+    z0_in_place = true;
+  } else if (lifted_chain_ok(m, ch.pu, 0)) {
+    ch.z0 = xin.ptr; ch.z0_stride = xin.ld;
+  } else {
+    NK_TRY(launch_copy2d(ctx, xin.ptr, xin.ld, Zall, ldz, batch, m));
+    z0_in_place = true;
+  }
+  NK_TRY(rollout_steps(ctx, ch, z0_in_place));
+  NK_TRY(launch_gemm(ctx, false, true, (int64_t)batch * T, d, m, 1.0, Zall, m, Cop, ldc, 0.0, xdev, ldxo));
+  if (out_z) NK_TRY(launch_copy2d(ctx, Zall, m, zdev, ldzo, (int64_t)batch * T, m));
+  if (!small) {
+    NK_TRY(finish_out(ctx, ox));
+    if (out_z) NK_TRY(finish_out(ctx, oz));
+  }
+  NK_HIP(hipStreamSynchronize(ctx->stream));
+  if (small) small_finish(st);
+  return NK_OK;
+}
+
 int nk_rollout(nk_ctx* ctx, const nk_model* mdl, const double* x0, int64_t ldx0, const double* U, int32_t T,
                int32_t batch, double* out_x, double* out_z) {
   NK_TRY(check_ctx(ctx));
@@ -1152,84 +1445,101 @@ int nk_rollout(nk_ctx* ctx, const nk_model* mdl, const double* x0, int64_t ldx0,
   NK_REQUIRE(T >= 1 && batch >= 1 && ldx0 >= mdl->d, "nk_rollout: bad sizes");
   const int m = mdl->m, d = mdl->d, p = mdl->p, mp = m + p;
   NK_REQUIRE(p == 0 || T == 1 || U != nullptr, "nk_rollout: controls missing");
-  MatIn x, u;
-  NK_TRY(stage_in(ctx, x0, ldx0, batch, d, &x));
-  if (p > 0 && T > 1) NK_TRY(stage_in(ctx, U, (int64_t)T * p, batch, (int64_t)T * p, &u));
-  MatOut ox, oz;
-  NK_TRY(stage_out(ctx, out_x, d, (int64_t)batch * T, d, &ox));
-  double* Zall = nullptr;  // [batch][T][m]
-  if (out_z) {
-    NK_TRY(stage_out(ctx, out_z, m, (int64_t)batch * T, m, &oz));
-    NK_REQUIRE(oz.ld == m || oz.host != nullptr, "nk_rollout: internal layout");
+  return rollout_impl(ctx, mdl, mdl->A, mp, mdl->C, m, m, d, p, x0, ldx0, nullptr, U, T, batch, out_x, out_z);
+}
+
+int nk_linear_rollout(nk_ctx* ctx, const double* A, const double* B, const double* Cop, int32_t m, int32_t d, int32_t p,
+                      const double* z0, const double* U, int32_t T, int32_t batch, double* out_x, double* out_z) {
+  NK_TRY(check_ctx(ctx));
+  NK_REQUIRE(A && Cop && z0 && out_x, "nk_linear_rollout: null argument");
+  NK_REQUIRE(m >= 1 && d >= 1 && p >= 0 && T >= 1 && batch >= 1, "nk_linear_rollout: bad sizes");
+  NK_REQUIRE(p == 0 || (B != nullptr && (T == 1 || U != nullptr)), "nk_linear_rollout: B or controls missing");
+  const int mp = m + p;
+  const int64_t ldg = mp + (mp & 1);
+  double* G = nullptr;
+  NK_TRY(arena_alloc_t(ctx, (size_t)m * ldg, &G));
+  MatIn a, b, c;
+  NK_TRY(stage_in(ctx, A, m, m, m, &a));
+  NK_TRY(launch_copy2d(ctx, a.ptr, a.ld, G, ldg, m, m));
+  if (p > 0) {
+    NK_TRY(stage_in(ctx, B, p, m, p, &b));
+    NK_TRY(launch_copy2d(ctx, b.ptr, b.ld, G + m, ldg, m, p));
   }
-  if (out_z && oz.ld == m) Zall = oz.dev;
-  else NK_TRY(arena_alloc_t(ctx, (size_t)batch * T * m, &Zall));
-  const int64_t ldz = (int64_t)T * m;
-  NK_TRY(lift_device(ctx, mdl, x.ptr, x.ld, batch, Zall, ldz));  // z_0 = phi(x_0) for every trajectory
-  for (int t = 0; t + 1 < T; ++t) {
-    // z_{t+1} = A z_t + B u_t      (benchmark_lqr_cloth.py:30)
-    if (batch <= 16) {  // matrix-vector chain: one wave per row of [A | B], trajectories in groups of 8
-      for (int b0 = 0; b0 < batch; b0 += 8) {
-        const int nb = batch - b0 < 8 ? batch - b0 : 8;
-        NK_TRY(launch_lifted_step(ctx, mdl->A, mp, m, m, p, Zall + (int64_t)b0 * ldz + (int64_t)t * m, ldz,
-                                  p > 0 ? u.ptr + (int64_t)b0 * u.ld + (int64_t)t * p : nullptr, u.ld, nullptr,
-                                  Zall + (int64_t)b0 * ldz + (int64_t)(t + 1) * m, ldz, nb));
-      }
-    } else {
-      NK_TRY(launch_gemm(ctx, false, true, batch, m, m, 1.0, Zall + (int64_t)t * m, ldz, mdl->A, mp, 0.0,
-                         Zall + (int64_t)(t + 1) * m, ldz));
-      if (p > 0)
-        NK_TRY(launch_gemm(ctx, false, true, batch, m, p, 1.0, u.ptr + (int64_t)t * p, u.ld, mdl->B, mp, 1.0,
-                           Zall + (int64_t)(t + 1) * m, ldz));
-    }
+  NK_TRY(stage_in(ctx, Cop, m, d, m, &c));
+  return rollout_impl(ctx, nullptr, G, ldg, c.ptr, c.ld, m, d, p, nullptr, 0, z0, U, T, batch, out_x, out_z);
+}
+
+int nk_closed_loop_batch(nk_ctx* ctx, const nk_model* mdl, const double* K, const double* phi0, const double* phi_ref,
+                         int32_t steps, int32_t batch, double* out_x, double* out_u) {
+  NK_TRY(check_ctx(ctx));
+  NK_REQUIRE(mdl && K && phi0 && phi_ref && out_x && out_u, "nk_closed_loop: null argument");
+  NK_REQUIRE(mdl->has_ops && steps >= 1 && batch >= 1 && mdl->p > 0, "nk_closed_loop: bad model or sizes");
+  const int m = mdl->m, d = mdl->d, p = mdl->p, mp = m + p;
+  const size_t need = pad256((size_t)p * m) + 2 * pad256((size_t)batch * m) + pad256((size_t)batch * steps * d) +
+                      pad256((size_t)batch * steps * p);
+  const bool small = need <= SMALL_STAGE_LIMIT && !is_device_ptr(K) && !is_device_ptr(phi0) && !is_device_ptr(phi_ref) &&
+                     !is_device_ptr(out_x) && !is_device_ptr(out_u);
+  SmallStage st;
+  st.ctx = ctx;
+  MatIn k, f0, fr;
+  MatOut ox, ou;
+  double *xdev = nullptr, *udev = nullptr;
+  int64_t ldxo = d, lduo = p;
+  if (small) {
+    NK_TRY(small_reserve(ctx, need));
+    k.ptr = small_in(st, K, m, p, m); k.ld = m;
+    f0.ptr = small_in(st, phi0, m, batch, m); f0.ld = m;
+    fr.ptr = small_in(st, phi_ref, m, batch, m); fr.ld = m;
+    xdev = small_out(st, out_x, d, (int64_t)batch * steps, d);
+    udev = small_out(st, out_u, p, (int64_t)batch * steps, p);
+  } else {
+    NK_TRY(stage_in(ctx, K, m, p, m, &k));
+    NK_TRY(stage_in(ctx, phi0, m, batch, m, &f0));
+    NK_TRY(stage_in(ctx, phi_ref, m, batch, m, &fr));
+    NK_TRY(stage_out(ctx, out_x, d, (int64_t)batch * steps, d, &ox));
+    NK_TRY(stage_out(ctx, out_u, p, (int64_t)batch * steps, p, &ou));
+    xdev = ox.dev; udev = ou.dev; ldxo = ox.ld; lduo = ou.ld;
   }
-  NK_TRY(launch_gemm(ctx, false, true, (int64_t)batch * T, d, m, 1.0, Zall, m, mdl->C, m, 0.0, ox.dev, ox.ld));
-  if (out_z && Zall != oz.dev) NK_TRY(launch_copy2d(ctx, Zall, m, oz.dev, oz.ld, (int64_t)batch * T, m));
-  NK_TRY(finish_out(ctx, ox));
-  if (out_z) NK_TRY(finish_out(ctx, oz));
+  // phi_{t+1} = A phi_t + B K (phi_ref - phi_t) = (A - B K) phi_t + B K phi_ref: one matrix-vector step per time step
+  // (algebraically the loop of benchmark_lqr_cloth.py:79-84; the controls u_t = K (phi_ref - phi_t) are recovered for all
+  // steps at once afterwards)
+  double *Phi = nullptr, *Acl = nullptr, *kref = nullptr, *cvec = nullptr, *Dm = nullptr;
+  NK_TRY(arena_alloc_t(ctx, (size_t)batch * steps * m, &Phi));
+  NK_TRY(arena_alloc_t(ctx, (size_t)m * m, &Acl));
+  NK_TRY(arena_alloc_t(ctx, (size_t)batch * p + 8, &kref));
+  NK_TRY(arena_alloc_t(ctx, (size_t)batch * m, &cvec));
+  NK_TRY(arena_alloc_t(ctx, (size_t)batch * steps * m, &Dm));
+  NK_TRY(launch_copy2d(ctx, mdl->A, mp, Acl, m, m, m));
+  NK_TRY(launch_gemm(ctx, false, false, m, m, p, -1.0, mdl->B, mp, k.ptr, k.ld, 1.0, Acl, m));     // A - B K
+  NK_TRY(launch_gemm(ctx, false, true, batch, p, m, 1.0, fr.ptr, fr.ld, k.ptr, k.ld, 0.0, kref, p));  // K phi_ref
+  NK_TRY(launch_gemm(ctx, false, true, batch, m, p, 1.0, kref, p, mdl->B, mp, 0.0, cvec, m));         // B K phi_ref
+  ChainArgs ch;
+  ch.G = Acl; ch.ldg = m; ch.m = m; ch.pu = 0; ch.T = steps; ch.batch = batch; ch.Zall = Phi;
+  ch.z_stride = (int64_t)steps * m; ch.bias = cvec; ch.bias_stride = m;
+  bool z0_in_place = false;
+  if (lifted_chain_ok(m, 0, 0)) {
+    ch.z0 = f0.ptr; ch.z0_stride = f0.ld;
+  } else {
+    NK_TRY(launch_copy2d(ctx, f0.ptr, f0.ld, Phi, ch.z_stride, batch, m));
+    z0_in_place = true;
+  }
+  NK_TRY(rollout_steps(ctx, ch, z0_in_place));
+  // u_t = K (phi_ref - phi_t) for all t: D = 1 phi_ref^T - Phi, U = D K^T
+  NK_TRY(launch_ref_minus_traj(ctx, fr.ptr, fr.ld, Phi, ch.z_stride, Dm, ch.z_stride, steps, m, batch));
+  NK_TRY(launch_gemm(ctx, false, true, (int64_t)batch * steps, p, m, 1.0, Dm, m, k.ptr, k.ld, 0.0, udev, lduo));
+  NK_TRY(launch_gemm(ctx, false, true, (int64_t)batch * steps, d, m, 1.0, Phi, m, mdl->C, m, 0.0, xdev, ldxo));  // x_t = C phi_t
+  if (!small) {
+    NK_TRY(finish_out(ctx, ox));
+    NK_TRY(finish_out(ctx, ou));
+  }
   NK_HIP(hipStreamSynchronize(ctx->stream));
+  if (small) small_finish(st);
   return NK_OK;
 }
 
 int nk_closed_loop(nk_ctx* ctx, const nk_model* mdl, const double* K, const double* phi0, const double* phi_ref,
                    int32_t steps, double* out_x, double* out_u) {
-  NK_TRY(check_ctx(ctx));
-  NK_REQUIRE(mdl && K && phi0 && phi_ref && out_x && out_u, "nk_closed_loop: null argument");
-  NK_REQUIRE(mdl->has_ops && steps >= 1 && mdl->p > 0, "nk_closed_loop: bad model or sizes");
-  const int m = mdl->m, d = mdl->d, p = mdl->p, mp = m + p;
-  MatIn k, f0, fr;
-  NK_TRY(stage_in(ctx, K, m, p, m, &k));
-  NK_TRY(stage_in(ctx, phi0, m, 1, m, &f0));
-  NK_TRY(stage_in(ctx, phi_ref, m, 1, m, &fr));
-  MatOut ox, ou;
-  NK_TRY(stage_out(ctx, out_x, d, steps, d, &ox));
-  NK_TRY(stage_out(ctx, out_u, p, steps, p, &ou));
-  // phi_{t+1} = A phi_t + B K (phi_ref - phi_t) = (A - B K) phi_t + B K phi_ref: one matrix-vector step per time step
-  // (algebraically the loop of benchmark_lqr_cloth.py:79-84; the controls u_t = K (phi_ref - phi_t) are recovered for all
-  // steps at once afterwards)
-  double *Phi = nullptr, *Acl = nullptr, *kref = nullptr, *cvec = nullptr, *Dm = nullptr;
-  NK_TRY(arena_alloc_t(ctx, (size_t)(steps + 1) * m, &Phi));
-  NK_TRY(arena_alloc_t(ctx, (size_t)m * m, &Acl));
-  NK_TRY(arena_alloc_t(ctx, (size_t)p + 8, &kref));
-  NK_TRY(arena_alloc_t(ctx, (size_t)m, &cvec));
-  NK_TRY(arena_alloc_t(ctx, (size_t)steps * m, &Dm));
-  NK_TRY(launch_copy2d(ctx, f0.ptr, m, Phi, m, 1, m));
-  NK_TRY(launch_copy2d(ctx, mdl->A, mp, Acl, m, m, m));
-  NK_TRY(launch_gemm(ctx, false, false, m, m, p, -1.0, mdl->B, mp, k.ptr, k.ld, 1.0, Acl, m));              // A - B K
-  NK_TRY(launch_lifted_step(ctx, k.ptr, k.ld, p, m, 0, fr.ptr, m, nullptr, 0, nullptr, kref, p, 1));        // K phi_ref
-  NK_TRY(launch_lifted_step(ctx, mdl->B, mp, m, p, 0, kref, p, nullptr, 0, nullptr, cvec, m, 1));           // B K phi_ref
-  for (int t = 0; t < steps; ++t)
-    NK_TRY(launch_lifted_step(ctx, Acl, m, m, m, 0, Phi + (int64_t)t * m, m, nullptr, 0, cvec, Phi + (int64_t)(t + 1) * m,
-                              m, 1));
-  // u_t = K (phi_ref - phi_t) for all t: D = 1 phi_ref^T - Phi, U = D K^T
-  NK_TRY(launch_copy2d(ctx, fr.ptr, 0, Dm, m, steps, m));  // row stride 0: broadcast phi_ref to every row
-  NK_TRY(launch_axpby2d(ctx, -1.0, Phi, m, 1.0, Dm, m, steps, m));
-  NK_TRY(launch_gemm(ctx, false, true, steps, p, m, 1.0, Dm, m, k.ptr, k.ld, 0.0, ou.dev, ou.ld));
-  NK_TRY(launch_gemm(ctx, false, true, steps, d, m, 1.0, Phi, m, mdl->C, m, 0.0, ox.dev, ox.ld));  // x_t = C phi_t
-  NK_TRY(finish_out(ctx, ox));
-  NK_TRY(finish_out(ctx, ou));
-  NK_HIP(hipStreamSynchronize(ctx->stream));
-  return NK_OK;
+  return nk_closed_loop_batch(ctx, mdl, K, phi0, phi_ref, steps, 1, out_x, out_u);
 }
 
 int nk_gemm(nk_ctx* ctx, int transA, int transB, int64_t M, int64_t N, int64_t K, double alpha, const double* A,
@@ -1288,8 +1598,29 @@ int nk_solve_spd(nk_ctx* ctx, const double* P, int64_t ldp, int32_t m, const dou
   NK_TRY(arena_alloc_t(ctx, (size_t)m * ldw, &W));
   NK_TRY(launch_copy2d(ctx, p.ptr, p.ld, L, m, m, m));
   NK_TRY(launch_copy2d(ctx, r.ptr, r.ld, W, ldw, m, nrhs));
-  NK_TRY(cholesky_lower(ctx, L, m, m, Linv));
-  NK_TRY(cholesky_solve(ctx, L, m, m, Linv, W, ldw, nrhs));
+  int rc_chol = cholesky_lower(ctx, L, m, m, Linv);
+  if (getenv("NYSKOOP_FORCE_PINV")) rc_chol = NK_ERR_NOT_SPD;  // testing hook: always take the SVD path
+  if (rc_chol == NK_ERR_NOT_SPD && !ctx->strict_spd) {
+    // numerically singular: X = P^+ R with gelsd's cut-off, i.e. X^T = R^T P^+ (P symmetric)
+    double *Rt = nullptr, *Xt = nullptr;
+    NK_TRY(arena_alloc_t(ctx, (size_t)nrhs * m, &Rt));
+    NK_TRY(arena_alloc_t(ctx, (size_t)nrhs * m, &Xt));
+    NK_TRY(launch_transpose(ctx, r.ptr, r.ld, Rt, m, m, nrhs));
+    PinvInfo pi;
+    const double rcond_use = getenv("NYSKOOP_PINV_RCOND") ? atof(getenv("NYSKOOP_PINV_RCOND")) : 2.220446049250313e-16;
+    NK_TRY(pinv_right_divide(ctx, p.ptr, p.ld, m, Rt, m, nrhs, Xt, m, rcond_use, &pi));
+    if (getenv("NYSKOOP_PINV_TRACE"))
+      fprintf(stderr, "[nk pinv] rank %d of %d, sigma_max %.3e, smallest kept %.3e, smallest %.3e, %d sweeps\n", pi.rank, m,
+              pi.sigma_max, pi.sigma_min_kept, pi.sigma_min, pi.sweeps);
+    if (!pi.converged) {
+      set_error("nk_solve_spd: Jacobi SVD of the singular system did not converge in %d sweeps", pi.sweeps);
+      return NK_ERR_NO_CONVERGENCE;
+    }
+    NK_TRY(launch_transpose(ctx, Xt, m, W, ldw, nrhs, m));
+  } else {
+    NK_TRY(rc_chol);
+    NK_TRY(cholesky_solve(ctx, L, m, m, Linv, W, ldw, nrhs));
+  }
   NK_HIP(hipMemcpy2DAsync(X, (size_t)ldxo * 8, W, (size_t)ldw * 8, (size_t)nrhs * 8, (size_t)m,
                           is_device_ptr(X) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
   NK_HIP(hipStreamSynchronize(ctx->stream));

@@ -68,6 +68,8 @@ struct nk_ctx {
   nk::Arena* cur_arena = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int* d_info = nullptr;       // device flags for factorisation failures (one int per paired system)
+  unsigned long long* d_piv = nullptr;  // [min, max] Cholesky pivot per system slot (bit patterns), behind d_info's 4 slots
+  unsigned long long* h_piv = nullptr;  // pinned host mirror
   double* d_scalars = nullptr; // small device scratch for reductions (64 doubles)
   double* h_scalars = nullptr; // pinned host mirror
   int* h_info = nullptr;       // pinned host mirror of d_info (kept apart from h_scalars: both streams may be in flight)
@@ -75,6 +77,11 @@ struct nk_ctx {
   hipEvent_t ev[16];
   int num_cu = 256;
   int kmat_mode = 0;  // 0 auto (Gram form on MFMA for d >= 32), 1 always direct differences (NYSKOOP_KMAT=direct)
+  int strict_spd = 0; // 1: a non-positive Cholesky pivot is an error (NK_ERR_NOT_SPD) instead of entering the
+                      // rank-truncating pseudo-inverse path (NYSKOOP_STRICT_SPD=1 / nk_set_strict_spd)
+  hipEvent_t ev_ext = nullptr;  // ordering against a caller's stream (nk_wait_stream)
+  double* h_stage = nullptr;    // page-locked, device-visible staging block for the small latency-bound calls (rollouts):
+  size_t h_stage_bytes = 0;     // kernels read their inputs from it and write their results into it directly (no DMA)
 };
 
 struct nk_model {
@@ -234,9 +241,40 @@ bool launch_chol_panel_pair(nk_ctx* ctx, const GemmCall* calls, int ncalls, int*
 // E_q <- E_q L_q^-1 on the extra rows of up to two factored systems, one launch (nk_trsm.hip)
 int launch_trsm_right_lower_pair(nk_ctx* ctx, const CholSys* sys, int nsys);
 
+// E_out (rows x m) = E * pinv(P) for symmetric P with LAPACK gelsd's cut-off (singular values <= rcond * sigma_max are
+// dropped): one-sided Jacobi SVD on the device (nk_pinv.hip), the fallback of the regularised solves
+struct PinvInfo {
+  int rank = 0, sweeps = 0;
+  bool converged = false;
+  double sigma_max = 0.0, sigma_min_kept = 0.0, sigma_min = 0.0;
+};
+int pinv_right_divide(nk_ctx* ctx, const double* P, int64_t ldp, int m, const double* E, int64_t lde, int rows,
+                      double* E_out, int64_t ldeo, double rcond, PinvInfo* info);
+// which systems of the last (paired) factorisation on the current stream met a non-positive pivot (synchronises)
+int cholesky_fail_flags(nk_ctx* ctx, const CholSys* sys, int nsys, int* failed /* nsys entries */, double tau_factor);
+
 // matrix-vector step of the lifted recursion for up to 8 trajectories (nk_rollout.hip)
 int launch_lifted_step(nk_ctx* ctx, const double* G, int64_t ldg, int m, int mz, int pu, const double* z, int64_t zstride,
                        const double* u, int64_t ustride, const double* bias, double* out, int64_t ostride, int batch);
+
+// the whole recursion z_{t+1} = G [z_t; u_t] + bias for a batch of trajectories in ONE launch, G resident in LDS (m <= 128);
+// optionally preceded by the lift of the initial states by the same workgroups (nk_rollout.hip)
+struct ChainArgs {
+  const double* G = nullptr; int64_t ldg = 0; int m = 0, pu = 0;
+  const double* z0 = nullptr; int64_t z0_stride = 0;
+  bool lift = false;
+  const double* x0 = nullptr; int64_t x0_stride = 0;
+  const double* Zl = nullptr; int d = 0; const double* winv = nullptr; const double* Sinv = nullptr; int ktype = 0;
+  double sigma0 = 0.0;
+  const double* U = nullptr; int64_t u_stride = 0;
+  const double* bias = nullptr; int64_t bias_stride = 0;
+  double* Zall = nullptr; int64_t z_stride = 0;
+  int T = 0, batch = 0;
+};
+int launch_ref_minus_traj(nk_ctx* ctx, const double* ref, int64_t ref_stride, const double* Phi, int64_t phi_stride,
+                          double* D, int64_t d_stride, int steps, int m, int batch);
+bool lifted_chain_ok(int m, int pu, int d_lift);
+int launch_lifted_chain(nk_ctx* ctx, const ChainArgs& a);
 
 }  // namespace nk
 

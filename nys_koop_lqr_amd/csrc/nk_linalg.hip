@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 
 namespace nk {
 
@@ -412,10 +413,22 @@ int sqrtm_spd_coupled(nk_ctx* ctx, const double* P, int64_t ldp, int m, double* 
 int launch_potrf_diag_pair(nk_ctx* ctx, double* const* Ajj, const int64_t* lda, const int* nb, double* const* Linv,
                            int nsys, int blk);
 
+// failure flags and [min, max] pivot slots of the current stream's two systems: flags <- 0, min <- +inf, max <- 0
+__global__ void reset_pivots_kernel(int* info, unsigned long long* piv) {
+  if (threadIdx.x < 4) piv[threadIdx.x] = (threadIdx.x & 1) ? 0ull : 0x7FF0000000000000ull;
+  if (threadIdx.x < 2) info[threadIdx.x] = 0;
+}
+static int reset_pivots(nk_ctx* ctx) {
+  hipLaunchKernelGGL(reset_pivots_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->d_info + info_base(ctx),
+                     ctx->d_piv + 2 * info_base(ctx));
+  NK_HIP(hipGetLastError());
+  return NK_OK;
+}
+
 int cholesky_lower_pair_async(nk_ctx* ctx, const CholSys* sys, int nsys) {
   constexpr int NB = CHOL_NB;
   NK_REQUIRE(nsys >= 1 && nsys <= 2, "cholesky_lower_pair: 1..2 systems");
-  NK_HIP(hipMemsetAsync(ctx->d_info + info_base(ctx), 0, 2 * sizeof(int), ctx->stream));
+  NK_TRY(reset_pivots(ctx));
   int nblk = 0;
   for (int q = 0; q < nsys; ++q) nblk = std::max(nblk, (sys[q].m + NB - 1) / NB);
   for (int jb = 0; jb < nblk; ++jb) {
@@ -463,16 +476,46 @@ int cholesky_lower_pair_async(nk_ctx* ctx, const CholSys* sys, int nsys) {
 
 // Host-side verdict of the factorisations queued by cholesky_lower_pair_async (synchronises the current stream).
 int cholesky_check_pair(nk_ctx* ctx, const CholSys* sys, int nsys) {
-  const int ib = info_base(ctx);
-  NK_HIP(hipMemcpyAsync(ctx->h_info + ib, ctx->d_info + ib, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-  NK_HIP(hipStreamSynchronize(ctx->stream));
-  const int* info = ctx->h_info + ib;
+  int failed[2] = {0, 0};
+  NK_TRY(cholesky_fail_flags(ctx, sys, nsys, failed, 8.0));
   for (int q = 0; q < nsys; ++q)
-    if (info[q] != 0) {
-      set_error("Cholesky: non-positive pivot at index %d of %d (system %d is numerically rank deficient; the "
-                "reference's lstsq would truncate here)", info[q] - 1, sys[q].m, q);
+    if (failed[q] != 0) {
+      if (failed[q] > 0)
+        set_error("Cholesky: non-positive pivot at index %d of %d (system %d is numerically rank deficient; the "
+                  "reference's lstsq would truncate here)", failed[q] - 1, sys[q].m, q);
+      else
+        set_error("Cholesky: pivots of system %d (order %d) span more than 1/(8 m eps): singular to working precision (the "
+                  "reference's lstsq would truncate here)", q, sys[q].m);
       return NK_ERR_NOT_SPD;
     }
+  return NK_OK;
+}
+
+// Verdict of the (paired) factorisation queued last on the current stream: failed[q] > 0 when system q met a
+// non-positive pivot (index + 1), -1 when its pivots say it is singular to working precision:
+// d_min <= tau_factor m eps d_max.  m eps |P| is the backward-error level of the factorisation, below which a pivot is
+// indistinguishable from zero (an exact null space -- duplicated landmarks, say -- shows up like this when rounding
+// happens to leave the pivot positive).  tau_factor: 1 inside a fit, whose right-hand sides have no component along such
+// a null space (the same duplicated landmarks annihilate them), so a rounding-level pivot is harmless and many merely
+// ill-conditioned hyper-parameter candidates have genuine pivots of 1e-13 d_max; 8 (a margin for d_max < |P|) for the
+// general-purpose nk_solve_spd, where an accepted rounding-level pivot multiplies an arbitrary right-hand side by 1e15.  The caller then
+// takes the SVD path, which applies gelsd's own rule (sigma <= eps sigma_max) to decide the rank, so a system that merely
+// looks suspicious here but is full rank by that rule is still solved at full rank.  Synchronises the current stream.
+int cholesky_fail_flags(nk_ctx* ctx, const CholSys* sys, int nsys, int* failed, double tau_factor) {
+  const int ib = info_base(ctx);
+  NK_HIP(hipMemcpyAsync(ctx->h_info + ib, ctx->d_info + ib, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  NK_HIP(hipMemcpyAsync(ctx->h_piv + 2 * ib, ctx->d_piv + 2 * ib, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost,
+                        ctx->stream));
+  NK_HIP(hipStreamSynchronize(ctx->stream));
+  for (int q = 0; q < nsys; ++q) {
+    failed[q] = ctx->h_info[ib + q];
+    if (failed[q] == 0) {
+      double dmin, dmax;
+      memcpy(&dmin, &ctx->h_piv[2 * (ib + q)], 8);
+      memcpy(&dmax, &ctx->h_piv[2 * (ib + q) + 1], 8);
+      if (dmax > 0.0 && dmin <= tau_factor * (double)sys[q].m * 2.220446049250313e-16 * dmax) failed[q] = -1;
+    }
+  }
   return NK_OK;
 }
 
@@ -488,7 +531,7 @@ int cholesky_lower_pair(nk_ctx* ctx, const CholSys* sys, int nsys) {
 int cholesky_aug_pair_async(nk_ctx* ctx, const CholSys* sys, int nsys, hipEvent_t mark, int mark_step) {
   constexpr int NB = CHOL_NB;
   NK_REQUIRE(nsys >= 1 && nsys <= 2, "cholesky_aug_pair: 1..2 systems");
-  NK_HIP(hipMemsetAsync(ctx->d_info + info_base(ctx), 0, 2 * sizeof(int), ctx->stream));
+  NK_TRY(reset_pivots(ctx));
   int nblk = 0;
   for (int q = 0; q < nsys; ++q) nblk = std::max(nblk, (sys[q].m + NB - 1) / NB);
   for (int jb = 0; jb < nblk; ++jb) {

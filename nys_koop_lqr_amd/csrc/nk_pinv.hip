@@ -1,0 +1,302 @@
+// Rank-revealing fallback of the two regularised solves (regressors.py:155,165): the reference calls
+// scipy.linalg.lstsq, i.e. LAPACK gelsd, which returns the MINIMUM-NORM solution with every singular value below a
+// cut-off relative to the largest one treated as zero.  The fast path (blocked Cholesky, nk_linalg.hip) has no such
+// notion: on a numerically rank-deficient system it meets a non-positive (or rounding-level) pivot.  This file provides
+// the truncated pseudo-inverse for that case, entirely on the device:
+//
+//   one-sided (Hestenes) Jacobi SVD of the symmetric m x m matrix P.  W starts as P, V as I, both stored so that logical
+//   column j is memory row j (P is symmetric, so W_0 = P needs no transpose).  A rotation of the pair (p, q) makes rows p
+//   and q of W orthogonal and is applied to the same rows of V; at convergence  P V = W^T  with mutually orthogonal
+//   columns u_j = row j of W, sigma_j = |u_j|, hence
+//        P^+ = sum_{sigma_j > rcond * sigma_max}  sigma_j^-2  v_j u_j^T ,     E P^+ = ((E V) diag(sigma^-2 | 0)) W .
+//   A sweep is m-1 rounds of m/2 independent pairs (round-robin tournament order), one launch per round and one
+//   workgroup per pair; the host reads one counter per sweep.  The iteration runs to full convergence (every pair
+//   orthogonal to m * eps): one-sided Jacobi then resolves an exact null space to ~1e-20 sigma_max (measured on the
+//   duplicated-landmark systems of tests/golden/f9), far below the cut-off, where bidiagonalisation-based LAPACK drivers
+//   leave it at (0.1..5) eps sigma_max, on either side of it (the same golden records gelsd keeping 41 singular values
+//   of a rank-40 matrix).  Columns a factor 1000 below the cut-off are left out of further rotations.
+//
+// Cut-off: gelsd's, as the reference calls it (scipy.linalg.lstsq default): singular values <= eps * sigma_max are dropped
+// -- plus the isolated-cluster rule documented at pinv_scale_kernel for matrices with an exact null space, whose
+// rounding-level singular values a general symmetric matrix leaves at (1..50) eps sigma_max even under Jacobi.
+//
+// This is the rare path: a 500 x 500 system takes ~20 sweeps = 10^4 small launches (tens of milliseconds), a 2000 x 2000
+// one about a second; it is never entered when the Cholesky succeeds with pivots above the rounding level.
+#include "nk_common.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+
+namespace nk {
+
+__device__ __forceinline__ double wave_sum_p(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+// round-robin tournament over N players (N even): round r in [0, N-1), pair k in [0, N/2)
+__device__ __forceinline__ void rr_pair(int N, int r, int k, int* a, int* b) {
+  if (k == 0) {
+    *a = N - 1;
+    *b = r;
+  } else {
+    *a = (r + k) % (N - 1);
+    *b = (r - k + (N - 1)) % (N - 1);
+  }
+}
+
+__global__ void __launch_bounds__(256) jacobi_round_kernel(double* __restrict__ W, double* __restrict__ V, int m, int N,
+                                                           int round, double tol,
+                                                           const double* __restrict__ d_small2,
+                                                           int* __restrict__ rot_count) {
+  __shared__ double sh[3][4];
+  __shared__ double cs_sn[2];
+  int p, q;
+  rr_pair(N, round, blockIdx.x, &p, &q);
+  if (p >= m || q >= m) return;  // the dummy player of an odd m
+  if (p > q) { const int t = p; p = q; q = t; }
+  double* wp = W + (int64_t)p * m;
+  double* wq = W + (int64_t)q * m;
+  double a = 0.0, b = 0.0, c = 0.0;
+  for (int k = threadIdx.x; k < m; k += 256) {
+    const double x = wp[k], y = wq[k];
+    a = fma(x, x, a);
+    b = fma(y, y, b);
+    c = fma(x, y, c);
+  }
+  a = wave_sum_p(a); b = wave_sum_p(b); c = wave_sum_p(c);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { sh[0][w] = a; sh[1][w] = b; sh[2][w] = c; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    a = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3];
+    b = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
+    c = sh[2][0] + sh[2][1] + sh[2][2] + sh[2][3];
+    double cs = 1.0, sn = 0.0;
+    const double small2 = d_small2[0];
+    const bool dead = a < small2 || b < small2;  // a column below the cut-off takes no further part
+    if (!dead && c != 0.0 && fabs(c) > tol * sqrt(a) * sqrt(b)) {
+      const double zeta = (b - a) / (2.0 * c);
+      const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+      cs = 1.0 / sqrt(1.0 + t * t);
+      sn = cs * t;
+      atomicAdd(rot_count, 1);
+    }
+    cs_sn[0] = cs;
+    cs_sn[1] = sn;
+  }
+  __syncthreads();
+  const double cs = cs_sn[0], sn = cs_sn[1];
+  if (sn == 0.0) return;
+  double* vp = V + (int64_t)p * m;
+  double* vq = V + (int64_t)q * m;
+  for (int k = threadIdx.x; k < m; k += 256) {
+    const double x = wp[k], y = wq[k];
+    wp[k] = cs * x - sn * y;
+    wq[k] = sn * x + cs * y;
+    const double vx = vp[k], vy = vq[k];
+    vp[k] = cs * vx - sn * vy;
+    vq[k] = sn * vx + cs * vy;
+  }
+}
+
+// sig2[j] = |row j of W|^2, one wave per row
+__global__ void __launch_bounds__(256) row_sumsq_kernel(const double* __restrict__ W, int m, double* __restrict__ sig2) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= m) return;
+  double s = 0.0;
+  for (int k = threadIdx.x & 63; k < m; k += 64) {
+    const double x = W[(int64_t)row * m + k];
+    s = fma(x, x, s);
+  }
+  s = wave_sum_p(s);
+  if ((threadIdx.x & 63) == 0) sig2[row] = s;
+}
+
+// d_small2[0] = (rcond * max_j |row j of W|)^2: the running estimate of the cut-off (max column norm <= sigma_max, and it
+// converges to sigma_max as the columns become orthogonal).  One workgroup.
+__global__ void __launch_bounds__(256) dead_threshold_kernel(const double* __restrict__ sig2, int m, double rcond,
+                                                             double* __restrict__ d_small2) {
+  __shared__ double shmax[4];
+  double mx = 0.0;
+  for (int j = threadIdx.x; j < m; j += 256) mx = fmax(mx, sig2[j]);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mx = fmax(mx, __shfl_down(mx, off, 64));
+  if ((threadIdx.x & 63) == 0) shmax[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) d_small2[0] = rcond * rcond * fmax(fmax(shmax[0], shmax[1]), fmax(shmax[2], shmax[3]));
+}
+
+// scale[j] = 1 / sigma_j^2 for the singular values that are kept, else 0; out[0] = rank, out[1] = sigma_max,
+// out[2] = smallest retained sigma, out[3] = smallest sigma.  One workgroup.
+// Cut-off: rcond * sigma_max (gelsd's rule).  One refinement: singular values up to window * sigma_max
+// (window = 8 m eps) are within the rounding noise of the decomposition itself; if ALL singular values in that window
+// form a cluster that a factor >= 1000 separates from the rest of the spectrum, the cluster is the image of an exact
+// null space (its members would otherwise land on either side of the cut-off by chance -- and a kept one multiplies the
+// right-hand side by 1e15) and is dropped as a whole.  A spectrum that decays continuously through the window, as those
+// of the ill-conditioned kernel systems do, has no such gap and gets gelsd's rule unchanged.
+__global__ void __launch_bounds__(256) pinv_scale_kernel(const double* __restrict__ sig2, int m, double rcond,
+                                                         double window, double* __restrict__ scale,
+                                                         double* __restrict__ out) {
+  __shared__ double sh[4];
+  __shared__ int shcnt[4];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  auto block_max = [&](double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, 64));
+    __syncthreads();
+    if (lane == 0) sh[w] = v;
+    __syncthreads();
+    return fmax(fmax(sh[0], sh[1]), fmax(sh[2], sh[3]));
+  };
+  auto block_min = [&](double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_down(v, off, 64));
+    __syncthreads();
+    if (lane == 0) sh[w] = v;
+    __syncthreads();
+    return fmin(fmin(sh[0], sh[1]), fmin(sh[2], sh[3]));
+  };
+  double mx = 0.0;
+  for (int j = threadIdx.x; j < m; j += 256) mx = fmax(mx, sig2[j]);
+  const double smax = sqrt(block_max(mx));
+  const double wtop = window * smax;
+  double hi = 1e300, cmax = 0.0;
+  for (int j = threadIdx.x; j < m; j += 256) {
+    const double s = sqrt(sig2[j]);
+    if (s > wtop) hi = fmin(hi, s); else cmax = fmax(cmax, s);
+  }
+  hi = block_min(hi);
+  cmax = block_max(cmax);
+  double cut = rcond * smax;
+  if (cmax > cut && hi < 1e300 && hi >= 1000.0 * cmax) cut = wtop;  // an isolated rounding-level cluster: drop it whole
+  int cnt = 0;
+  double mn = 1e300, keepmin = 1e300;
+  for (int j = threadIdx.x; j < m; j += 256) {
+    const double s = sqrt(sig2[j]);
+    mn = fmin(mn, s);
+    if (s > cut) {
+      scale[j] = 1.0 / sig2[j];
+      keepmin = fmin(keepmin, s);
+      ++cnt;
+    } else {
+      scale[j] = 0.0;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, 64);
+  __syncthreads();
+  if (lane == 0) shcnt[w] = cnt;
+  mn = block_min(mn);
+  keepmin = block_min(keepmin);
+  if (threadIdx.x == 0) {
+    out[0] = (double)(shcnt[0] + shcnt[1] + shcnt[2] + shcnt[3]);
+    out[1] = smax;
+    out[2] = keepmin;
+    out[3] = mn;
+  }
+}
+
+__global__ void scale_cols_kernel(double* __restrict__ T, int64_t ldt, int rows, int cols, const double* __restrict__ scale) {
+  const int64_t total = (int64_t)rows * cols;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = e / cols, c = e - r * cols;
+    T[r * ldt + c] *= scale[c];
+  }
+}
+
+__global__ void sumsq_all_kernel(const double* __restrict__ P, int64_t ldp, int m, double* __restrict__ out) {
+  __shared__ double sh[4];
+  double s = 0.0;
+  const int64_t total = (int64_t)m * m;
+  for (int64_t e = threadIdx.x; e < total; e += 256) {
+    const int64_t r = e / m, c = e - r * m;
+    const double v = P[r * ldp + c];
+    s = fma(v, v, s);
+  }
+  s = wave_sum_p(s);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// E_out (rows x m) = E (rows x m) * pinv(P) with gelsd's singular-value cut-off `rcond` (relative to the largest one).
+// P: symmetric m x m (device).  Synchronises the current stream (one host round trip per sweep).
+int pinv_right_divide(nk_ctx* ctx, const double* P, int64_t ldp, int m, const double* E, int64_t lde, int rows,
+                      double* E_out, int64_t ldeo, double rcond, PinvInfo* info) {
+  const ArenaMark mk = arena_mark(ctx);
+  const size_t mm = (size_t)m * m;
+  double *W = nullptr, *V = nullptr, *sig2 = nullptr, *scale = nullptr, *T = nullptr, *d_out = nullptr;
+  int* d_rot = nullptr;
+  NK_TRY(arena_alloc_t(ctx, mm, &W));
+  NK_TRY(arena_alloc_t(ctx, mm, &V));
+  NK_TRY(arena_alloc_t(ctx, (size_t)m, &sig2));
+  NK_TRY(arena_alloc_t(ctx, (size_t)m, &scale));
+  NK_TRY(arena_alloc_t(ctx, (size_t)(rows > 0 ? rows : 1) * m, &T));
+  NK_TRY(arena_alloc_t(ctx, (size_t)8, &d_out));
+  NK_TRY(arena_alloc_t(ctx, (size_t)2, &d_rot));
+  NK_TRY(launch_copy2d(ctx, P, ldp, W, m, m, m));
+  NK_TRY(launch_fill(ctx, V, m, m, m, 0.0));
+  NK_TRY(launch_add_diag(ctx, V, m, m, 1.0));
+  hipLaunchKernelGGL(sumsq_all_kernel, dim3(1), dim3(256), 0, ctx->stream, P, ldp, m, d_out);
+  NK_HIP(hipGetLastError());
+  NK_HIP(hipMemcpyAsync(ctx->h_scalars, d_out, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  NK_HIP(hipStreamSynchronize(ctx->stream));
+  const double fro = std::sqrt(ctx->h_scalars[0]);
+  if (!std::isfinite(fro)) {
+    set_error("pseudo-inverse fallback: the system matrix is not finite");
+    arena_release(ctx, mk);
+    return NK_ERR_NOT_SPD;
+  }
+  const double tol = 2.220446049250313e-16 * (double)(m > 64 ? m : 64);  // orthogonality target, above the rounding level
+                                                                         // of an m-term dot product
+  const int N = m + (m & 1);
+  const int max_sweeps = 60;
+  const bool trace = getenv("NYSKOOP_PINV_TRACE") != nullptr;
+  // columns this far below the cut-off take no further part (they are dropped, and leaving them unconverged perturbs P by
+  // less than 1e-3 eps sigma_max); NYSKOOP_PINV_DEAD overrides the factor for experiments
+  const double dead_rel = getenv("NYSKOOP_PINV_DEAD") ? atof(getenv("NYSKOOP_PINV_DEAD")) : 1e-3 * rcond;
+  int sweeps = 0, last_rot = -1;
+  if (m > 1) {
+    for (; sweeps < max_sweeps; ++sweeps) {
+      NK_HIP(hipMemsetAsync(d_rot, 0, sizeof(int), ctx->stream));
+      // refresh the dead-column threshold from the current column norms
+      hipLaunchKernelGGL(row_sumsq_kernel, dim3((m + 3) / 4), dim3(256), 0, ctx->stream, W, m, sig2);
+      hipLaunchKernelGGL(dead_threshold_kernel, dim3(1), dim3(256), 0, ctx->stream, sig2, m, dead_rel, d_out + 4);
+      for (int r = 0; r < N - 1; ++r)
+        hipLaunchKernelGGL(jacobi_round_kernel, dim3(N / 2), dim3(256), 0, ctx->stream, W, V, m, N, r, tol, d_out + 4, d_rot);
+      NK_HIP(hipGetLastError());
+      NK_HIP(hipMemcpyAsync(ctx->h_info + 8, d_rot, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+      NK_HIP(hipStreamSynchronize(ctx->stream));
+      last_rot = ctx->h_info[8];
+      if (trace) fprintf(stderr, "[nk pinv] m=%d sweep %d: %d rotations\n", m, sweeps, last_rot);
+      if (last_rot == 0) { ++sweeps; break; }
+    }
+  }
+  hipLaunchKernelGGL(row_sumsq_kernel, dim3((m + 3) / 4), dim3(256), 0, ctx->stream, W, m, sig2);
+  hipLaunchKernelGGL(pinv_scale_kernel, dim3(1), dim3(256), 0, ctx->stream, sig2, m, rcond,
+                     8.0 * (double)m * 2.220446049250313e-16, scale, d_out);
+  NK_HIP(hipGetLastError());
+  if (rows > 0) {
+    NK_TRY(launch_gemm(ctx, false, true, rows, m, m, 1.0, E, lde, V, m, 0.0, T, m));  // T = E V   (V^T stored: rows v_j)
+    hipLaunchKernelGGL(scale_cols_kernel, dim3(256), dim3(256), 0, ctx->stream, T, (int64_t)m, rows, m, scale);
+    NK_HIP(hipGetLastError());
+    NK_TRY(launch_gemm(ctx, false, false, rows, m, m, 1.0, T, m, W, m, 0.0, E_out, ldeo));  // (T diag) W, rows of W = u_j
+  }
+  NK_HIP(hipMemcpyAsync(ctx->h_scalars, d_out, 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  NK_HIP(hipStreamSynchronize(ctx->stream));
+  if (info) {
+    info->rank = (int)ctx->h_scalars[0];
+    info->sigma_max = ctx->h_scalars[1];
+    info->sigma_min_kept = ctx->h_scalars[2];
+    info->sigma_min = ctx->h_scalars[3];
+    info->sweeps = sweeps;
+    info->converged = last_rot == 0 || m <= 1;
+  }
+  arena_release(ctx, mk);
+  return NK_OK;
+}
+
+}  // namespace nk

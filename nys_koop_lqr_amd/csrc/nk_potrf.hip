@@ -30,6 +30,8 @@ struct PotrfBatch {
   int nb[2];
   double* Linv[2];
   int* info[2];
+  unsigned long long* piv[2];  // [min, max] pivot of the whole factorisation as bit patterns (positive doubles order like
+                               // their bit patterns): the numerical-rank verdict d_min <= eps * d_max
 };
 
 constexpr int PLD = CHOL_NB + 1;  // LDS row stride of the 64 x 64 images
@@ -66,6 +68,7 @@ __global__ void __launch_bounds__(64) potrf_diag_kernel(PotrfBatch pb, int blk) 
   const int64_t lda = pb.lda[which];
   double* __restrict__ Linv = pb.Linv[which];
   int* __restrict__ info = pb.info[which];
+  double piv_min = 1.0e308, piv_max = 0.0;
   __shared__ double As[NB * PLD];
   __shared__ double Iv[NB * PLD];
   __shared__ double Sc[3 * 16 * SLD];
@@ -95,6 +98,9 @@ __global__ void __launch_bounds__(64) potrf_diag_kernel(PotrfBatch pb, int blk) 
       if (!(dkk > 0.0) || !isfinite(dkk)) {
         if (lane == 0 && c0 + k < nb) atomicCAS(info, 0, blk * NB + c0 + k + 1);
         dkk = 1.0;
+      } else if (c0 + k < nb) {
+        piv_min = fmin(piv_min, dkk);
+        piv_max = fmax(piv_max, dkk);
       }
       // sqrt and reciprocal without the library routines (about 45 dependent fp64 VALU instructions per pivot between
       // them, more than the whole panel update): hardware rsq seed, two Newton steps, one Heron correction
@@ -203,6 +209,10 @@ __global__ void __launch_bounds__(64) potrf_diag_kernel(PotrfBatch pb, int blk) 
   // dense 64 x 64 row-major inverse, exact zeros above the block diagonal
 #pragma unroll 8
   for (int i = 0; i < NB; ++i) Linv[i * NB + lane] = (l4 <= (i >> 4)) ? Iv[i * PLD + lane] : 0.0;
+  if (lane == 0 && piv_max > 0.0) {
+    atomicMin(pb.piv[which], (unsigned long long)__double_as_longlong(piv_min));
+    atomicMax(pb.piv[which] + 1, (unsigned long long)__double_as_longlong(piv_max));
+  }
 }
 
 // Ajj/lda/nb/Linv: per system (nb <= 0 skips a system); failures are flagged in ctx->d_info[info_base + system]
@@ -216,6 +226,7 @@ int launch_potrf_diag_pair(nk_ctx* ctx, double* const* Ajj, const int64_t* lda, 
     pb.nb[q] = on ? nb[q] : 0;
     pb.Linv[q] = on ? Linv[q] : nullptr;
     pb.info[q] = ctx->d_info + info_base(ctx) + q;
+    pb.piv[q] = ctx->d_piv + 2 * (info_base(ctx) + q);
   }
   hipLaunchKernelGGL(potrf_diag_kernel, dim3(2), dim3(64), 0, ctx->stream, pb, blk);
   NK_HIP(hipGetLastError());

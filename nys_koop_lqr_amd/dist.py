@@ -57,9 +57,11 @@ def all_gather_scores(local_scores, n_units, rank, world):
     return out
 
 
-def sharded_grid_search(X, Y, n_inputs, candidates, n_splits=5, centers=None, unit_fn=None, seed=None, workers=1):
+def sharded_grid_search(X, Y, n_inputs, candidates, n_splits=5, centers=None, unit_fn=None, seed=None, workers=1,
+                        error_score=np.nan):
     """Distributed counterpart of harness.grid_search_cv.  Landmarks: `centers[(c, f)]` if given, otherwise drawn
     from a per-unit RandomState(seed + unit index) so that the result does not depend on the world size.
+    A unit whose fit fails numerically scores `error_score` (nan by default, like GridSearchCV) and the sweep goes on.
     Every rank returns the same dict (split_scores, mean_test_score, best_index, best_params)."""
     import torch.distributed as dist
     rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_initialized() else (0, 1)
@@ -77,6 +79,8 @@ def sharded_grid_search(X, Y, n_inputs, candidates, n_splits=5, centers=None, un
             n_train = X.shape[0] - (folds[f][1] - folds[f][0])
             rs = np.random.RandomState((0 if seed is None else int(seed)) + u)
             idx = rs.choice(np.arange(0, n_train), size=candidates[c]["m"], replace=False)
+        if unit_fn is harness.cv_unit_score:
+            return unit_fn(X, Y, n_inputs, candidates[c], folds[f], idx, error_score)
         return unit_fn(X, Y, n_inputs, candidates[c], folds[f], idx)
 
     if workers > 1 and len(mine) > 1:  # several latency-bound fits in flight per GPU (one context per thread)
@@ -89,9 +93,9 @@ def sharded_grid_search(X, Y, n_inputs, candidates, n_splits=5, centers=None, un
     else:
         flat = np.asarray(local, dtype=np.float64)
     scores = flat.reshape(len(candidates), n_splits)
-    mean = scores.mean(axis=1)
-    best = int(np.argmax(mean))
-    return dict(split_scores=scores, mean_test_score=mean, best_index=best, best_params=candidates[best])
+    mean, best = harness._rank_candidates(scores)  # a failed (NaN) candidate ranks last, as in GridSearchCV
+    return dict(split_scores=scores, mean_test_score=mean, best_index=best,
+                best_params=candidates[best] if best >= 0 else None)
 
 
 def sample_sharded_fit(reg, X_local, Y_local, landmark_rows=None):
@@ -152,8 +156,13 @@ def sample_sharded_fit(reg, X_local, Y_local, landmark_rows=None):
             gram = torch.from_numpy(_lib.pinned_empty((cnt,)))
         except Exception:
             gram = torch.empty(cnt, dtype=torch.float64)
+    # Stream ordering (device path): gram_partial returns with the accumulator complete (the library synchronises its
+    # stream before returning); the all-reduce runs on RCCL's stream, which torch orders after its current stream, and
+    # `fit_from_gram` orders the library's (non-blocking) streams after torch's current stream (nk_wait_stream through
+    # Context.wait_for) -- and torch's current stream after the collective through work.wait() -- before it reads the sum.
     reg.gram_partial(X_local, Y_local, out=gram if use_cuda else gram.numpy())
     if world > 1:
-        dist.all_reduce(gram)
+        work = dist.all_reduce(gram, async_op=True)
+        work.wait()  # nccl: torch's current stream now waits for the collective; gloo: blocks until done
     reg.fit_from_gram(gram if use_cuda else gram.numpy(), n_total, d)
     return reg

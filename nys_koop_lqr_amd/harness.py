@@ -11,11 +11,23 @@ from . import _lib
 from .regressors import KoopmanNystromRegressor
 
 
+def open_loop_forecast(regressor, true_trajectory, test_controls):
+    """The simulated trajectory of validate_dyn_sys (benchmark_lqr_cloth.py:23-32): lift the first state, then
+    z <- A z + B u_i for i < T-1, x = C z; T = number of columns of the true trajectory.  Only the first T-1 control
+    columns are used, so `test_controls` may have T-1 columns (benchmark_lqr_hjb.py:129-139 builds them that way) or more."""
+    T = true_trajectory.shape[1]
+    U = np.asarray(test_controls, dtype=np.float64)[:, :T]
+    if U.shape[1] < T - 1:
+        raise ValueError(f"{T - 1} control columns needed, got {U.shape[1]}")
+    if U.shape[1] == T - 1:  # the rollout call takes one column per state; the last one is never read
+        U = np.hstack((U, np.zeros((U.shape[0], 1))))
+    return regressor.rollout(true_trajectory[:, 0], U)
+
+
 def validate_dyn_sys(regressor, true_trajectory, test_controls, relative=False):
     """benchmark_lqr_cloth.py:18-36 (absolute RMSE, :34); relative=True gives the %-form of
     benchmark_lqr_classic.py:39 / benchmark_lqr_hjb.py:42."""
-    T = true_trajectory.shape[1]
-    sim = regressor.rollout(true_trajectory[:, 0], np.asarray(test_controls)[:, :T])
+    sim = open_loop_forecast(regressor, true_trajectory, test_controls)
     if relative:
         return np.sqrt(np.sum(np.square(true_trajectory - sim))) / np.sqrt(np.sum(np.square(sim))) * 100
     return np.sqrt(np.mean(np.square(true_trajectory - sim)))
@@ -44,9 +56,11 @@ def cv_work_list(n_candidates, n_splits):
     return [(c, f) for c in range(n_candidates) for f in range(n_splits)]
 
 
-def cv_unit_score(X, Y, n_inputs, params, fold, centers_idx=None):
+def cv_unit_score(X, Y, n_inputs, params, fold, centers_idx=None, error_score=np.nan):
     """One (candidate, fold) unit: fit on the training rows (two contiguous ranges, no copy), score the held-out
-    rows with sklearn's 'neg_root_mean_squared_error' reduced on the device."""
+    rows with sklearn's 'neg_root_mean_squared_error' reduced on the device.  A fit that fails numerically
+    (LinAlgError: only possible in strict mode, or when the square-root iteration diverges) scores `error_score`,
+    like GridSearchCV's default error_score=nan; error_score='raise' re-raises."""
     n = X.shape[0]
     lo, hi = fold
     n_train = n - (hi - lo)
@@ -56,11 +70,27 @@ def cv_unit_score(X, Y, n_inputs, params, fold, centers_idx=None):
     centers_idx = np.asarray(centers_idx)
     rows = np.where(centers_idx < lo, centers_idx, centers_idx + (hi - lo))  # training-row index -> dataset row
     reg.nystrom_centers_output = np.asarray(Y)[rows].T
-    reg.fit(X, Y, row_ranges=[(0, lo), (hi, n)])
-    return reg.score_neg_rmse(X[lo:hi], Y[lo:hi])
+    try:
+        reg.fit(X, Y, row_ranges=[(0, lo), (hi, n)])
+        return reg.score_neg_rmse(X[lo:hi], Y[lo:hi])
+    except (np.linalg.LinAlgError, _lib.NyskoopError) as e:
+        if isinstance(error_score, str) and error_score == "raise":
+            raise
+        if isinstance(e, _lib.NyskoopError) and e.code != -5:  # only numerical failures are scored; the rest is a bug
+            raise
+        return float(error_score)
 
 
-def grid_search_cv(X, Y, n_inputs, candidates, n_splits=5, centers=None, work=None, workers=1):
+def _rank_candidates(scores):
+    """mean_test_score, best_index as GridSearchCV computes them: a candidate with a failed (NaN) fold has a NaN mean and
+    ranks last; best = first candidate with the highest finite mean (-1 if every candidate failed)."""
+    mean = scores.mean(axis=1)
+    finite = np.isfinite(mean)
+    best = int(np.argmax(np.where(finite, mean, -np.inf))) if finite.any() else -1
+    return mean, best
+
+
+def grid_search_cv(X, Y, n_inputs, candidates, n_splits=5, centers=None, work=None, workers=1, error_score=np.nan):
     """learn_hyperparams (benchmark_lqr_cloth.py:39-66 and the classic/hjb twins) without sklearn's process pool.
 
     candidates: list of dicts with keys kernel / gamma / m.  centers: optional {(c, f): landmark indices into the
@@ -68,7 +98,8 @@ def grid_search_cv(X, Y, n_inputs, candidates, n_splits=5, centers=None, work=No
     sklearn with n_jobs=1 exactly.  work: optional subset of (candidate, fold) units (for sharding over GPUs); units
     not evaluated are NaN.  workers: host threads issuing units concurrently on this GPU (each thread has its own
     context and streams; small fits are latency bound, so several in flight fill the chip).  The landmark draws happen
-    up front in GridSearchCV's order, so the scores do not depend on `workers`.
+    up front in GridSearchCV's order, so the scores do not depend on `workers`.  error_score: score of a unit whose fit
+    fails numerically (GridSearchCV's default: nan; such a candidate ranks last), or 'raise'.
     Returns split_scores (n_cand x n_splits), mean_test_score, best_index.
     """
     X = np.ascontiguousarray(X, dtype=np.float64)
@@ -89,7 +120,7 @@ def grid_search_cv(X, Y, n_inputs, candidates, n_splits=5, centers=None, work=No
 
     def run(item):
         c, f, idx = item
-        return c, f, cv_unit_score(X, Y, n_inputs, candidates[c], folds[f], idx)
+        return c, f, cv_unit_score(X, Y, n_inputs, candidates[c], folds[f], idx, error_score)
 
     if workers > 1 and len(todo) > 1:
         results = list(_lib.worker_pool(workers).map(run, todo))
@@ -97,19 +128,62 @@ def grid_search_cv(X, Y, n_inputs, candidates, n_splits=5, centers=None, work=No
         results = [run(item) for item in todo]
     for c, f, sc in results:
         scores[c, f] = sc
-    mean = scores.mean(axis=1)
-    best = int(np.nanargmax(mean)) if np.all(np.isfinite(mean)) else -1
+    if work is None:
+        mean, best = _rank_candidates(scores)
+    else:  # a shard: the caller assembles the full table
+        mean, best = scores.mean(axis=1), -1
     return dict(split_scores=scores, mean_test_score=mean, best_index=best,
                 best_params=candidates[best] if best >= 0 else None)
 
 
-def lqr_control(num_steps, reference, initial_state, regressor, K):
-    """Lifted closed loop of benchmark_lqr_cloth.py:69-84: returns (visited_states (d, 1+num_steps) starting with the
-    initial state, u_ops (p, num_steps))."""
-    phi_new = regressor.lift(initial_state)
-    phi_reference = regressor.lift(reference)
-    xs, us = regressor.closed_loop(K, phi_new, phi_reference, num_steps)
-    return np.hstack((initial_state.reshape(-1, 1), xs)), us
+def lqr_closed_loop(num_steps, reference, initial_state, regressor, K):
+    """The loop of benchmark_lqr_cloth.py:73-84 alone: returns (visited_states (d, 1+num_steps) starting with the initial
+    state, u_ops (p, num_steps)).  One device call (lifts of both states + the whole lifted recursion)."""
+    initial_state = np.asarray(initial_state, dtype=np.float64).reshape(-1, 1)
+    reference = np.asarray(reference, dtype=np.float64).reshape(-1, 1)
+    phi = regressor.lift(np.hstack((initial_state, reference)))  # one call for both lifts
+    xs, us = regressor.closed_loop(K, phi[:, 0], phi[:, 1], num_steps)
+    return np.hstack((initial_state, xs)), us
+
+
+def lqr_control(num_steps, reference, initial_state, regressor, K, control_nodes=(168, 169, 170, 189, 190, 191),
+                simulator_order=(0, 3, 1, 4, 2, 5)):
+    """benchmark_lqr_cloth.py:69-104 in full: the lifted closed loop, the CUMULATIVE input sequence seeded with the
+    positions of the two controlled corner nodes (`u_s[:, 0] = initial_state[control_nodes]`, every later column adds
+    the step's u_op, :76-81), the per-axis split of the visited states (x = rows 0,3,6.., y = 1,4,.., z = 2,5,..; :85-101)
+    and the input rows permuted for the MATLAB simulator (:102).  Returns (x_s, y_s, z_s, final_us) with
+    x_s, y_s, z_s: (d/3, 1+num_steps), final_us: (p, 1+num_steps)."""
+    initial_state = np.asarray(initial_state, dtype=np.float64).reshape(-1, 1)
+    visited, u_ops = lqr_closed_loop(num_steps, reference, initial_state, regressor, K)
+    u0 = initial_state[list(control_nodes), :]
+    u_s = np.hstack((u0, u0 + np.cumsum(u_ops, axis=1)))
+    x_s, y_s, z_s = visited[0::3], visited[1::3], visited[2::3]
+    final_us = u_s[list(simulator_order), :]
+    return x_s, y_s, z_s, final_us
+
+
+def lqr_control_plant(num_steps, reference, initial_state, regressor, K, plant_step):
+    """The plant-in-the-loop variant of benchmark_lqr_hjb.py:73-97 (and _classic.py:67-89): u = K (phi(ref) - phi(x)),
+    x <- plant_step(x, u), phi re-lifted from the true state every step (one cached-square-root lift per step instead of
+    the reference's O(m^3) sqrtm).  plant_step(x (d,1), u (p,1)) -> x_next.  Returns (x_s (num_steps,), u_s (p, num_steps))
+    like the reference: x_s is the first state coordinate of the visited states."""
+    x = np.asarray(initial_state, dtype=np.float64).reshape(-1, 1)
+    phi_ref = regressor.lift(np.asarray(reference, dtype=np.float64).reshape(-1, 1))
+    phi = regressor.lift(x)
+    xs, us = [], []
+    for _ in range(num_steps):
+        u = K @ (phi_ref - phi)
+        us.append(u.reshape(-1, 1))
+        xs.append(x[0, 0])
+        x = np.asarray(plant_step(x, u), dtype=np.float64).reshape(-1, 1)
+        phi = regressor.lift(x)
+    return np.array(xs), np.hstack(us)
+
+
+def control_rmse_percent(us, u_opt):
+    """benchmark_lqr_hjb.py:313 / :378."""
+    us, u_opt = np.asarray(us).squeeze(), np.asarray(u_opt).squeeze()
+    return np.sqrt(np.sum(np.square(us - u_opt))) / np.sqrt(np.sum(np.square(u_opt))) * 100
 
 
 def create_data_matrices(trajs, controls, indices):

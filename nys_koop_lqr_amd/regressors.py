@@ -17,6 +17,42 @@ def _is_device_tensor(x):
     return hasattr(x, "data_ptr") and hasattr(x, "stride")
 
 
+def linear_rollout(A, B, C, z0, controls, return_lifted=False):
+    """Open-loop recursion z_{t+1} = A z_t + B u_t, x_t = C z_t on the device for explicit operators (nk_linear_rollout).
+
+    z0: (m,) / (m, 1) with controls (p, T) -> simulated (d, T) [and lifted (m, T)]; column 0 is C z0 and the last control
+    column is not used, exactly like the loop of validate_dyn_sys (benchmark_lqr_cloth.py:23-32).
+    z0: (batch, m) with controls (batch, T, p) -> (batch, T, d) [and (batch, T, m)]."""
+    ctx = _lib.get_context()
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    C_ = np.ascontiguousarray(C, dtype=np.float64)
+    m, d = A.shape[0], C_.shape[0]
+    B = np.asarray(B, dtype=np.float64)
+    B = np.ascontiguousarray(B.reshape(m, B.size // m))
+    p = B.shape[1]
+    if A.shape != (m, m) or C_.shape != (d, m):
+        raise ValueError(f"operator shapes {A.shape}, {B.shape}, {C_.shape} do not fit together")
+    controls = np.asarray(controls, dtype=np.float64)
+    single = controls.ndim == 2
+    if single:
+        z0b = np.ascontiguousarray(np.asarray(z0, dtype=np.float64).reshape(1, m))
+        U = np.ascontiguousarray(controls.T).reshape(1, controls.shape[1], p)
+    else:
+        z0b = np.ascontiguousarray(np.asarray(z0, dtype=np.float64).reshape(-1, m))
+        U = np.ascontiguousarray(controls)
+    batch, T = U.shape[0], U.shape[1]
+    if U.shape != (batch, T, p) or z0b.shape[0] != batch:
+        raise ValueError(f"controls have shape {U.shape}, expected {(z0b.shape[0], T, p)}")
+    out_x = np.empty((batch, T, d))
+    out_z = np.empty((batch, T, m)) if return_lifted else None
+    _lib.check(ctx.lib.nk_linear_rollout(ctx.handle, A.ctypes.data, B.ctypes.data if p else None, C_.ctypes.data, m, d, p,
+                                         z0b.ctypes.data, U.ctypes.data if p else None, T, batch, out_x.ctypes.data,
+                                         None if out_z is None else out_z.ctypes.data))
+    if single:
+        return (out_x[0].T, out_z[0].T) if return_lifted else out_x[0].T
+    return (out_x, out_z) if return_lifted else out_x
+
+
 class KoopmanRegressor(BaseEstimator):
     """regressors.py:32-55."""
 
@@ -35,6 +71,12 @@ class KoopmanRegressor(BaseEstimator):
     def fit(self, X, Y):
         raise NotImplementedError
 
+    def rollout(self, x0, controls, return_lifted=False):
+        """Open-loop forecast of validate_dyn_sys (benchmark_lqr_cloth.py:23-32; benchmark_lqr_hjb.py:23-44) for any
+        estimator that provides `lift`, `A`, `B`, `C`: x0 (d,) with controls (p, T) -> simulated (d, T)."""
+        z0 = self.lift(np.asarray(x0, dtype=np.float64).reshape(-1, 1))
+        return linear_rollout(self.A, self.B, self.C, z0, controls, return_lifted)
+
     def predict(self, X_aug):
         """regressors.py:48-55 for a subclass that only provides `lift` and `weights`: the product W [phi; u] runs
         on the device through nk_gemm."""
@@ -52,7 +94,9 @@ class KoopmanRegressor(BaseEstimator):
 def _fetched(name):
     """Operator attribute of a fitted Nystrom regressor: `fit` queues the device->host copies and returns; the first
     access waits for them (nk_model_wait), so a sweep that fits the next candidate right away overlaps the copies of
-    one fit with the kernels of the next."""
+    one fit with the kernels of the next.  Assigning an operator bumps a version counter that is part of the key of the
+    cached device model, so predict / rollout never run on stale device copies; an IN-PLACE edit (`reg.A[0, 0] = 1`)
+    cannot be seen -- follow it with `reg.A = reg.A` (or `reg.invalidate_device_model()`)."""
     key = "_" + name
 
     def get(self):
@@ -62,6 +106,7 @@ def _fetched(name):
     def set_(self, value):
         self._wait_fetch()
         self.__dict__[key] = value
+        self.__dict__["_ops_version"] = self.__dict__.get("_ops_version", 0) + 1
 
     return property(get, set_)
 
@@ -90,8 +135,13 @@ class KoopmanNystromRegressor(KoopmanRegressor):
         self._model = None
         self._model_key = None
         self._stats = None
+        self._ops_version = 0
 
     # ------------------------------------------------------------------------------------------------ plumbing
+    def invalidate_device_model(self):
+        """Forget the device copy of landmarks and operators (rebuilt from the host attributes at the next use)."""
+        self._wait_fetch()
+        self._drop_model()
     def _wait_fetch(self):
         if self.__dict__.get("_fetching"):
             self.__dict__["_fetching"] = False
@@ -113,6 +163,7 @@ class KoopmanNystromRegressor(KoopmanRegressor):
         self.__dict__.setdefault("_model", None)
         self.__dict__.setdefault("_model_key", None)
         self.__dict__.setdefault("_stats", None)
+        self.__dict__.setdefault("_ops_version", 0)
 
     def __del__(self):
         try:
@@ -236,6 +287,7 @@ class KoopmanNystromRegressor(KoopmanRegressor):
         t_host0 = time.perf_counter()
         self._drop_model()
         t_host1 = time.perf_counter()
+        ctx.wait_for(X, Y)  # device tensors: whatever torch still has queued for them comes first
         rc = ctx.lib.nk_nystrom_fit(ctx.handle, C.byref(kd), Xm.ptr, Xm.ld, Ym.ptr, Ym.ld, n, d, p, rr, n_rr,
                                     None if same else Zi.ctypes.data, d, Zo.ctypes.data, d, m,
                                     float(self.gamma), float(self.jitter), C.byref(h), C.byref(stats))
@@ -277,6 +329,7 @@ class KoopmanNystromRegressor(KoopmanRegressor):
             optr = out.ctypes.data
         rr, n_rr, keep_rr = self._ranges(row_ranges)
         stats = _lib.FitStats()
+        ctx.wait_for(X, Y, out)
         rc = ctx.lib.nk_nystrom_gram(ctx.handle, C.byref(kd), Xm.ptr, Xm.ld, Ym.ptr, Ym.ld, n, d, p, rr, n_rr,
                                      None if same else Zi.ctypes.data, d, Zo.ctypes.data, d, m, optr, C.byref(stats))
         self._raise(ctx, rc)
@@ -305,6 +358,7 @@ class KoopmanNystromRegressor(KoopmanRegressor):
         t_host0 = time.perf_counter()
         self._drop_model()
         t_host1 = time.perf_counter()
+        ctx.wait_for(gram)  # e.g. the output of an all-reduce still running on torch's (RCCL's) stream
         rc = ctx.lib.nk_nystrom_solve(ctx.handle, C.byref(kd), None if same else Zi.ctypes.data, d, Zo.ctypes.data, d, m,
                                       d, p, gptr, int(n_total), float(self.gamma), float(self.jitter), C.byref(h),
                                       C.byref(stats))
@@ -312,8 +366,10 @@ class KoopmanNystromRegressor(KoopmanRegressor):
         self._adopt(ctx, h, stats, m, d, p, (t_host0, t_host1))
 
     def _ops_key(self):
-        d = self.__dict__
-        return (id(self.nystrom_centers_output), id(d.get("_A")), id(d.get("_B")), id(d.get("_C")), id(d.get("_weights")))
+        # landmarks are a plain attribute (the reference's callers assign them): identity + shape; operators: the
+        # version counter bumped by every assignment (ids alone could be reused by a new array after a free)
+        z = self.nystrom_centers_output
+        return (id(z), None if z is None else np.shape(z), self.__dict__.get("_ops_version", 0))
 
     # ------------------------------------------------------------------------------------------------ lift / predict
     def lift(self, X):
@@ -324,6 +380,7 @@ class KoopmanNystromRegressor(KoopmanRegressor):
         nq = Xq.shape[0]
         m = np.asarray(self.nystrom_centers_output).shape[1]
         out = np.empty((nq, m))
+        ctx.wait_for(X)
         _lib.check(ctx.lib.nk_lift(ctx.handle, h, Xq.ptr, Xq.ld, nq, out.ctypes.data, m))
         return out.T
 
@@ -336,6 +393,7 @@ class KoopmanNystromRegressor(KoopmanRegressor):
         if Xm.shape[1] != d + int(self.n_inputs):
             raise ValueError(f"X_aug has {Xm.shape[1]} columns, expected {d + int(self.n_inputs)}")
         out = np.empty((Xm.shape[0], d))
+        ctx.wait_for(X_aug)
         _lib.check(ctx.lib.nk_predict(ctx.handle, h, Xm.ptr, Xm.ld, Xm.shape[0], out.ctypes.data, d))
         return out
 
@@ -345,7 +403,15 @@ class KoopmanNystromRegressor(KoopmanRegressor):
         ctx = _lib.get_context()
         h = self._ensure_model()
         Xm, Ym = _lib.Mat(X_aug), _lib.Mat(Y)
+        d = np.asarray(self.nystrom_centers_output).shape[0]
+        if Xm.shape[1] != d + int(self.n_inputs):
+            raise ValueError(f"X_aug has {Xm.shape[1]} columns, expected {d + int(self.n_inputs)}")
+        if Ym.shape != (Xm.shape[0], d):
+            raise ValueError(f"Y has shape {Ym.shape}, expected {(Xm.shape[0], d)}")
+        if Xm.shape[0] == 0:
+            raise ValueError("score_neg_rmse needs at least one row")
         s = C.c_double()
+        ctx.wait_for(X_aug, Y)
         _lib.check(ctx.lib.nk_score_neg_rmse(ctx.handle, h, Xm.ptr, Xm.ld, Ym.ptr, Ym.ld, Xm.shape[0], C.byref(s)))
         return s.value
 
@@ -377,21 +443,34 @@ class KoopmanNystromRegressor(KoopmanRegressor):
         return (out_x, out_z) if return_lifted else out_x
 
     def closed_loop(self, K, phi0, phi_ref, num_steps):
-        """Lifted closed loop of lqr_control (benchmark_lqr_cloth.py:79-84): returns (visited (d, steps),
-        u_ops (p, steps))."""
+        """Lifted closed loop of lqr_control (benchmark_lqr_cloth.py:79-84).
+
+        phi0, phi_ref: (m,) / (m, 1)  -> (visited (d, steps), u_ops (p, steps));
+        phi0, phi_ref: (batch, m)     -> (visited (batch, steps, d), u_ops (batch, steps, p)): independent loops that share
+        the gain (several initial states / references in one call)."""
         ctx = _lib.get_context()
         h = self._ensure_model()
         d, m = np.asarray(self.nystrom_centers_output).shape
         p = int(self.n_inputs)
         K = np.ascontiguousarray(K, dtype=np.float64)
-        f0 = np.ascontiguousarray(np.asarray(phi0, dtype=np.float64).reshape(m))
-        fr = np.ascontiguousarray(np.asarray(phi_ref, dtype=np.float64).reshape(m))
         if K.shape != (p, m):
             raise ValueError(f"gain has shape {K.shape}, expected {(p, m)}")
-        ox, ou = np.empty((num_steps, d)), np.empty((num_steps, p))
-        _lib.check(ctx.lib.nk_closed_loop(ctx.handle, h, K.ctypes.data, f0.ctypes.data, fr.ctypes.data, int(num_steps),
-                                          ox.ctypes.data, ou.ctypes.data))
-        return ox.T, ou.T
+        phi0 = np.asarray(phi0, dtype=np.float64)
+        phi_ref = np.asarray(phi_ref, dtype=np.float64)
+        single = phi0.ndim < 2 or phi0.shape[1] == 1  # a vector or the (m, 1) column that `lift` returns
+        if single:
+            f0 = np.ascontiguousarray(phi0.reshape(1, m))
+            fr = np.ascontiguousarray(phi_ref.reshape(1, m))
+        else:
+            f0 = np.ascontiguousarray(phi0.reshape(-1, m))
+            fr = np.ascontiguousarray(np.broadcast_to(phi_ref.reshape(-1, m), f0.shape))
+        batch = f0.shape[0]
+        ox, ou = np.empty((batch, num_steps, d)), np.empty((batch, num_steps, p))
+        _lib.check(ctx.lib.nk_closed_loop_batch(ctx.handle, h, K.ctypes.data, f0.ctypes.data, fr.ctypes.data,
+                                                int(num_steps), batch, ox.ctypes.data, ou.ctypes.data))
+        if single:
+            return ox[0].T, ou[0].T
+        return ox, ou
 
     def solve_lqr(self, Q=None, R=None, c=0.0075):
         """Host DARE, standing in for control.dlqr(A, B, Q, R) (benchmark_lqr_cloth.py:238-240,262): by default

@@ -269,6 +269,84 @@ def lqr_closed_loop_lifted(A, B, C, K, phi0, phi_ref, num_steps):
     return np.hstack(xs), np.hstack(us)
 
 
+def lqr_control_cloth(A, B, C, K, phi0, phi_ref, initial_state, num_steps, n_states=192):
+    """benchmark_lqr_cloth.py:69-104 after the two lifts (:73-74): the lifted loop with the CUMULATIVE input sequence
+    seeded from the control nodes (:76-81), the per-axis split (:85-101) and the simulator's row order (:102).
+    Returns (x_s, y_s, z_s, final_us)."""
+    initial_state = np.asarray(initial_state, dtype=np.float64).reshape(-1, 1)
+    phi_new = np.asarray(phi0, dtype=np.float64).reshape(-1, 1)
+    phi_reference = np.asarray(phi_ref, dtype=np.float64).reshape(-1, 1)
+    visited_states = initial_state
+    u_s = initial_state[[168, 169, 170, 189, 190, 191], :]
+    for _ in range(num_steps):
+        u_op = K @ (phi_reference - phi_new)
+        u_s = np.hstack((u_s, u_s[:, -1].reshape(-1, 1) + u_op))
+        visited_states = np.hstack((visited_states, C @ phi_new))
+        phi_new = A @ phi_new + B @ u_op
+    n_nodes = n_states // 3
+    x_s = np.zeros((n_nodes, visited_states.shape[1]))
+    y_s = np.zeros_like(x_s)
+    z_s = np.zeros_like(x_s)
+    for i in range(n_states):
+        (x_s, y_s, z_s)[i % 3][i // 3, :] = visited_states[i, :]
+    final_us = np.vstack((u_s[0, :], u_s[3, :], u_s[1, :], u_s[4, :], u_s[2, :], u_s[5, :]))
+    return x_s, y_s, z_s, final_us
+
+
+def lqr_control_plant(reg, K, plant_step, initial_state, reference, num_steps):
+    """benchmark_lqr_hjb.py:73-97: plant in the loop, the state re-lifted every step.  Returns (x_s, u_s (p, steps))."""
+    x = np.asarray(initial_state, dtype=np.float64).reshape(-1, 1)
+    phi_ref = reg.lift(np.asarray(reference, dtype=np.float64).reshape(-1, 1))
+    phi = reg.lift(x)
+    xs, us = [], []
+    for _ in range(num_steps):
+        u = K @ (phi_ref - phi)
+        us.append(u.reshape(-1, 1))
+        xs.append(x[0, 0])
+        x = np.asarray(plant_step(x, u)).reshape(-1, 1)
+        phi = reg.lift(x)
+    return np.array(xs), np.hstack(us)
+
+
+def hjb_optimal_controls(plant_step, x0, num_steps):
+    """The analytic optimum u* = x^3 - x sqrt(1 + x^4) rolled through the plant (benchmark_lqr_hjb.py:302-308)."""
+    x = np.array([[float(x0)]])
+    out = []
+    for _ in range(num_steps):
+        u = x ** 3 - x * np.sqrt(1 + x ** 4)
+        out.append(float(u.squeeze()))
+        x = plant_step(x, u)
+    return np.array(out)
+
+
+def cloth_reference_state(initial_state, alpha=np.pi / 4, vertical_shift=0.0, horizontal_shift=0.0):
+    """benchmark_lqr_cloth.py:241-255."""
+    x = np.asarray(initial_state, dtype=np.float64).reshape(-1, 1)
+    offset = np.zeros_like(x)
+    z_top = x[-1]
+    for i in range(x.shape[0]):
+        if i % 3 == 1:
+            r = abs(z_top - x[i + 1])
+            offset[i] = r * np.sin(alpha) + horizontal_shift
+        if i % 3 == 2:
+            r = abs(z_top - x[i])
+            offset[i] = r - r * np.cos(alpha) + vertical_shift
+    return x + offset
+
+
+def truncated_solve(P, R, rcond=None):
+    """What scipy.linalg.lstsq(P, R) (gelsd, regressors.py:155,165) computes in exact arithmetic: the minimum-norm
+    solution with singular values <= rcond * s_max dropped (rcond = machine epsilon by default), evaluated through
+    LAPACK's full SVD.  On a system with a clean spectral gap this is THE well-defined answer; gelsd's own internal SVD
+    sometimes keeps one rounding-level singular value of an exactly singular matrix (its computed value lands just above
+    eps * s_max) and then returns garbage along that direction -- tests/golden/f9_rank_deficient.npz records such a case.
+    Returns (X, rank)."""
+    rcond = np.finfo(np.float64).eps if rcond is None else rcond
+    U, s, Vt = np.linalg.svd(np.asarray(P, dtype=np.float64))
+    keep = s > rcond * s[0]
+    return (Vt[keep].T / s[keep]) @ (U[:, keep].T @ R), int(keep.sum())
+
+
 def kfold_slices(n, n_splits=5):
     """sklearn KFold(n_splits, shuffle=False): contiguous folds, the first n % k folds one longer."""
     sizes = np.full(n_splits, n // n_splits, dtype=int)

@@ -37,3 +37,13 @@ def test_readers_on_the_reference_files(golden):
     assert np.array_equal(trajs[10], g["trajs"][0]) and np.array_equal(ctrls[11], g["inputs"][1])
     X, Y = datasets.load_duffing(os.path.join(REF, "duffing"))
     assert X.shape == (3, 69900) and Y.shape == (2, 69900)
+
+
+def test_cloth_reference_state_matches_shipped_csv(golden):
+    """datasets.cloth_reference_state (benchmark_lqr_cloth.py:241-255) against the reference's shipped
+    8x8_cloth_swing_xyz/sim_results/nystrom/data/reference_lqr.csv (kept in the f10 golden; 5-digit CSV)."""
+    from nys_koop_lqr_amd import datasets
+    g = golden("f10_lqr_control.npz")
+    got = datasets.cloth_reference_state(g["initial_state"])
+    assert got.shape == g["reference_lqr"].shape
+    assert np.max(np.abs(got - g["reference_lqr"])) < 5e-6

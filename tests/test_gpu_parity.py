@@ -123,9 +123,18 @@ def test_sqrtm_and_solve_spd(nk, m):
     X = np.empty_like(R)
     _lib.check(ctx.lib.nk_solve_spd(ctx.handle, P.ctypes.data, m, m, R.ctypes.data, m + 3, m + 3, X.ctypes.data, m + 3))
     assert relf(X, np.linalg.solve(P, R)) < 1e-10
+    # not positive definite: by default the library answers like scipy.linalg.lstsq (regressors.py:155,165), here -R;
+    # in strict mode it reports NK_ERR_NOT_SPD
     bad = -np.eye(m)
-    with pytest.raises(_lib.NyskoopError):
-        _lib.check(ctx.lib.nk_solve_spd(ctx.handle, bad.ctypes.data, m, m, R.ctypes.data, m + 3, m + 3, X.ctypes.data, m + 3))
+    _lib.check(ctx.lib.nk_solve_spd(ctx.handle, bad.ctypes.data, m, m, R.ctypes.data, m + 3, m + 3, X.ctypes.data, m + 3))
+    assert relf(X, -R) < 1e-12
+    ctx.set_strict_spd(True)
+    try:
+        with pytest.raises(_lib.NyskoopError):
+            _lib.check(ctx.lib.nk_solve_spd(ctx.handle, bad.ctypes.data, m, m, R.ctypes.data, m + 3, m + 3, X.ctypes.data,
+                                            m + 3))
+    finally:
+        ctx.set_strict_spd(False)
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -591,19 +600,31 @@ def test_sample_sharded_fit_two_ranks_one_gpu(nk, O, golden, tmp_path):
 
 
 @pytest.mark.gpu
-def test_indefinite_system_is_reported_not_computed(nk, O, golden):
-    """A negative ridge makes the regularised normal matrix indefinite: the blocked Cholesky flags the pivot, the queued
-    substitutions / products run on garbage harmlessly, and the call returns NK_ERR_NOT_SPD (LinAlgError) at its end;
-    the context stays usable."""
+def test_indefinite_system_strict_error_or_lstsq_answer(nk, O, golden):
+    """A negative ridge makes the regularised normal matrix indefinite: the blocked Cholesky flags the pivot and the queued
+    substitutions / products run on garbage harmlessly.  In strict mode the call then returns NK_ERR_NOT_SPD
+    (LinAlgError) at its end; by default it does what the reference's lstsq does with such a matrix (regressors.py:155,165)
+    -- solve it through the SVD -- and matches the faithful oracle.  The context stays usable either way."""
     g = golden("f2_synth_rbf_d384.npz")
     X, Y = g["X"].astype(np.float64), g["Y"].astype(np.float64)
     d = Y.shape[1]
-    kern, _ = _kernels(nk, O, "rbf", g["ls"], d)
+    kern, okern = _kernels(nk, O, "rbf", g["ls"], d)
+    ctx = nk.get_context()
     bad = nk.KoopmanNystromRegressor(6, kernel=kern, gamma=-10.0, m=len(g["idx"]))
     bad.nystrom_centers_output = Y.T[:, g["idx"]]
-    with pytest.raises(np.linalg.LinAlgError):
-        bad.fit(X, Y)
+    ctx.set_strict_spd(True)
+    try:
+        with pytest.raises(np.linalg.LinAlgError):
+            bad.fit(X, Y)
+    finally:
+        ctx.set_strict_spd(False)
     assert bad._model is None
+    bad.fit(X, Y)
+    ref = O.KoopmanNystromOracle(6, kernel=okern, gamma=-10.0, m=len(g["idx"]))
+    ref.nystrom_centers_output = Y.T[:, g["idx"]]
+    ref.fit(X, Y)
+    assert relf(bad.predict(X[:64]), ref.predict(X[:64])) < 1e-6
+    assert bad.fit_stats_["rank_inner"] == len(g["idx"]) + 6
     reg, X, Y, d = _fit(nk, O, "rbf", g, 6)  # same context, next call
     assert relf(reg.A, g["A"]) < 1e-6
 

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol(lib):
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.nk_version() == 1
+    assert lib.nk_version() == 2
 
 
 def test_no_cpu_fallback(lib):
