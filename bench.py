@@ -12,8 +12,9 @@ receives device pointers).  With N > 1 every rank owns a full replica of the dat
 all-gather one diagnostic scalar per fit at the end (RCCL); value = total fits / max-over-ranks time ("weak" scaling).
 
 Rank 0 prints ONE JSON line carrying `roofline` (dominant kernel: the fp64-MFMA Gram GEMM, timed live with HIP events
-on the library's stream) and, at N=1, `cpu_baseline` (the NumPy/SciPy oracle in reference-faithful mode on a bounded
-row sample, extrapolated linearly in n for the n-proportional stages).
+on the library's stream) and, at N=1, `cpu_baseline` (the NumPy/SciPy oracle in reference-faithful mode: by default on
+the full workload, one warm-up + two timed fits, about two minutes; `--cpu-baseline sample` is the quick extrapolated
+form), `value_host_inputs` (host arrays in, host arrays out) and `cv_sweep` (the cloth-shaped hyper-parameter sweep).
 """
 import argparse
 import json
@@ -53,35 +54,113 @@ def gram_flops_syrk(n, m, p, d):
     return mp * (mp + 1) * n + 2.0 * m * mp * n + m * (m + 1) * n + 2.0 * d * m * n
 
 
-def cpu_baseline(X, Y, idx, ls, gamma, p, sample_rows, threads):
-    """Reference-faithful oracle on the first `sample_rows` rows with the full m landmarks; stages that scale with n
-    (kernel builds, Gram products) are extrapolated linearly to the full n, the O(m^3) stages are taken as measured."""
+def _oracle_fit(O, X, Y, Z, ls, gamma, p, faithful=True):
+    n, d = Y.shape
+    reg = O.KoopmanNystromOracle(p, kernel=O.ThreeDimensionalKernel(ls, ls, ls, d), gamma=gamma, m=Z.shape[0],
+                                 faithful=faithful)
+    reg.nystrom_centers_output = Z.T
+    t0 = time.perf_counter()
+    reg.fit(X, Y)
+    return time.perf_counter() - t0, reg
+
+
+def _blas_threads():
+    try:
+        from threadpoolctl import threadpool_info
+        return sorted({int(i.get("num_threads", 0)) for i in threadpool_info() if i.get("user_api") == "blas"})
+    except Exception:
+        return []
+
+
+def cpu_baseline_full(X, Y, idx, ls, gamma, p, threads, timed=2, budget_s=240.0):
+    """SURVEY 8(d) protocol: the reference-faithful oracle (cdist + exp, sqrtm x2, solve(her), lstsq x2) on the FULL
+    workload, one warm-up (a fit on a 10 % row sample with all landmarks: pages in SciPy / BLAS and spins up the thread
+    pool) and `timed` full-size fits; value = 1 / median.  The warm-up also predicts the cost of a full fit: on a host
+    where `timed` fits would not fit into `budget_s` seconds, fewer are run (at least one), and if even one would not
+    fit, the labelled sample extrapolation is reported instead -- the default run must finish within minutes anywhere."""
+    from oracle import nk_oracle as O
+    from threadpoolctl import threadpool_limits
+    n, d = Y.shape
+    Z = Y[idx]
+    rows = max(n // 10, len(idx))
+    with threadpool_limits(limits=threads):
+        blas = _blas_threads()
+        warm, wreg = _oracle_fit(O, X[:rows], Y[:rows], Z, ls, gamma, p)
+        tw = wreg.timings
+        predicted = tw["fixed"] + (tw["kernel_n"] + tw["gram_n"]) * (n / rows)
+        if predicted > budget_s:
+            return None
+        timed = max(1, min(timed, int(budget_s // predicted)))
+        walls, stages = [], None
+        for _ in range(timed):
+            w, reg = _oracle_fit(O, X, Y, Z, ls, gamma, p)
+            walls.append(w)
+            stages = reg.timings
+        fast = None
+        if predicted * (timed + 0.3) < budget_s:
+            fast, _ = _oracle_fit(O, X, Y, Z, ls, gamma, p, faithful=False)
+    med = float(np.median(walls))
+    return dict(value=1.0 / med, unit="fits/s", cores=threads, kind="port", protocol="full-size",
+                seconds_per_fit=walls, spread_rel=float((max(walls) - min(walls)) / med),
+                os_cpu_count=os.cpu_count(), blas_threads=blas, fast_mode_value=None if fast is None else 1.0 / fast,
+                sample=(f"oracle in reference-faithful mode (cdist+exp, sqrtm x2, solve(her), lstsq x2) on the full workload "
+                        f"n={n} m={len(idx)} d={d}: warm-up on a 10% row sample ({warm:.1f} s), then {timed} timed full-size "
+                        f"fit(s) {['%.1f' % w for w in walls]} s (last: {stages['kernel_n']:.1f} s kernel builds + "
+                        f"{stages['gram_n']:.1f} s Gram + {stages['fixed']:.1f} s O(m^3)); cdist/exp are single-threaded; "
+                        f"fast_mode_value = the same algebra with eigh square root + Cholesky"))
+
+
+def cpu_baseline_sample(X, Y, idx, ls, gamma, p, sample_rows, threads):
+    """Fallback (--cpu-baseline sample): faithful oracle on the first `sample_rows` rows with all landmarks; the stages
+    that scale with n (kernel builds, Gram products) are extrapolated linearly, the O(m^3) stages taken as measured."""
     from oracle import nk_oracle as O
     from threadpoolctl import threadpool_limits
     n, d = Y.shape
     Z = Y[idx]
     with threadpool_limits(limits=threads):
-        reg = O.KoopmanNystromOracle(p, kernel=O.ThreeDimensionalKernel(ls, ls, ls, d), gamma=gamma, m=len(idx))
-        reg.nystrom_centers_output = Z.T
-        t0 = time.perf_counter()
-        reg.fit(X[:sample_rows], Y[:sample_rows])
-        wall = time.perf_counter() - t0
-    tm = reg.timings
+        wall, reg = _oracle_fit(O, X[:sample_rows], Y[:sample_rows], Z, ls, gamma, p)
+        _, fast = _oracle_fit(O, X[:sample_rows], Y[:sample_rows], Z, ls, gamma, p, faithful=False)
+    tm, tf = reg.timings, fast.timings
     full = tm["fixed"] + (tm["kernel_n"] + tm["gram_n"]) * (n / sample_rows)
-    # the de-pessimised CPU form (eigh square root computed once + Cholesky solves), so that the speed-up is not
-    # inflated by the reference's avoidable O(m^3) work (SURVEY 8d)
-    with threadpool_limits(limits=threads):
-        fast = O.KoopmanNystromOracle(p, kernel=O.ThreeDimensionalKernel(ls, ls, ls, d), gamma=gamma, m=len(idx),
-                                      faithful=False)
-        fast.nystrom_centers_output = Z.T
-        fast.fit(X[:sample_rows], Y[:sample_rows])
-    tf = fast.timings
     full_fast = tf["fixed"] + (tf["kernel_n"] + tf["gram_n"]) * (n / sample_rows)
-    return dict(value=1.0 / full, unit="fits/s", cores=threads, kind="port", fast_mode_value=1.0 / full_fast,
-                sample=(f"oracle (faithful: cdist+exp, sqrtm x2, solve(her), lstsq x2) on the first {sample_rows} of {n} "
-                        f"rows with all {len(idx)} landmarks: {wall:.1f} s wall = {tm['kernel_n']:.1f} s kernel builds + "
-                        f"{tm['gram_n']:.1f} s Gram (both scaled x{n / sample_rows:.0f}) + {tm['fixed']:.1f} s O(m^3) "
-                        f"stages (unscaled) => {full:.0f} s per full fit; cdist/exp are single-threaded")), reg
+    return dict(value=1.0 / full, unit="fits/s", cores=threads, kind="port", protocol="extrapolated-sample",
+                os_cpu_count=os.cpu_count(), blas_threads=_blas_threads(), fast_mode_value=1.0 / full_fast,
+                sample=(f"EXTRAPOLATED: faithful oracle on the first {sample_rows} of {n} rows with all {len(idx)} landmarks: "
+                        f"{wall:.1f} s wall = {tm['kernel_n']:.1f} s kernel builds + {tm['gram_n']:.1f} s Gram (both scaled "
+                        f"x{n / sample_rows:.0f}) + {tm['fixed']:.1f} s O(m^3) stages (unscaled) => {full:.0f} s per full fit"))
+
+
+def cv_sweep_rate(nk, workers=4):
+    """Secondary figure: the hyper-parameter sweep of benchmark_lqr_cloth.py:39-66 at its real shape (n = 1010 rows in 5
+    folds, m = 500 landmarks, d = 192, p = 6; synthetic cloth-shaped rows) -- (candidate, fold) units per second."""
+    from nys_koop_lqr_amd import harness
+    rng = np.random.default_rng(7)
+    n, d, p, m = 1010, 192, 6, 500
+    S = rng.standard_normal((n, d)) * 0.3
+    U = rng.standard_normal((n, p)) * 0.05
+    Y = np.tanh(S @ (rng.standard_normal((d, d)) * 0.9 / np.sqrt(d))) + U @ (rng.standard_normal((p, d)) * 0.1)
+    X = np.hstack([S, U])
+    cands = [dict(kernel=nk.ThreeDimensionalKernel(l, l, l, d), gamma=g, m=m) for l in (3.0, 6.0, 12.0)
+             for g in (1e-6, 1e-5, 1e-4)]
+    centers = {(c, f): np.random.RandomState(17 * c + f).choice(808, m, replace=False) for c in range(9) for f in range(5)}
+    cands = cands * 4  # 180 units
+    centers = {(c, f): np.random.RandomState(17 * c + f).choice(808, m, replace=False) for c in range(len(cands))
+               for f in range(5)}
+    nu = len(cands) * 5
+    one = harness.grid_search_cv(X, Y, p, cands[:9], centers=centers)  # one unit at a time (also the bit-identity reference)
+    t0 = time.perf_counter()
+    harness.grid_search_cv(X, Y, p, cands[:9], centers=centers)
+    dt1 = time.perf_counter() - t0
+    harness.grid_search_cv(X, Y, p, cands, centers=centers, batch=30, batch_groups=3)  # warm-up of every group member
+    dt = 1e9
+    for _ in range(2):
+        t0 = time.perf_counter()
+        res = harness.grid_search_cv(X, Y, p, cands, centers=centers, batch=30, batch_groups=3)
+        dt = min(dt, time.perf_counter() - t0)
+    return dict(units_per_s=nu / dt, units=nu, seconds=dt, mode="lock-step batched: 3 groups x 30 units (nk_cv_grid)",
+                units_per_s_unbatched=45 / dt1, shape="n=1010 (808 train / 202 test) m=500 d=192 p=6",
+                bit_identical_to_unbatched=bool(np.array_equal(one["split_scores"], res["split_scores"][:9])),
+                finite=bool(np.all(np.isfinite(res["split_scores"]))))
 
 
 def main():
@@ -93,9 +172,17 @@ def main():
     ap.add_argument("--m", type=int, default=2000)
     ap.add_argument("--d", type=int, default=384)
     ap.add_argument("--p", type=int, default=6)
+    ap.add_argument("--cpu-baseline", choices=["full", "sample", "none"], default="full",
+                    help="full: faithful oracle on the full workload, warm-up + 2 timed fits (~2 min); sample: one fit on "
+                         "--cpu-sample-rows rows, extrapolated (labelled as such); none: skip")
     ap.add_argument("--cpu-sample-rows", type=int, default=10000)
-    ap.add_argument("--cpu-threads", type=int, default=16)
+    ap.add_argument("--cpu-threads", type=int, default=min(16, os.cpu_count() or 1))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sweep", action="store_true",
+                    help="N = 1 walks the same CV-grid candidate list as the N > 1 runs (step s fits candidate s mod 15), so "
+                         "that a 1 -> N scaling curve times the same workload; the headline line (default) fits l=20, "
+                         "gamma=1e-6 every step")
+    ap.add_argument("--no-extras", action="store_true", help="skip the host-input and CV-sweep secondary figures")
     ap.add_argument("--concurrency", type=int, default=1,
                     help="host threads issuing independent fits concurrently on each GPU (each with its own context and "
                          "streams); 1 = one fit at a time (the default, and the setting the roofline figure refers to)")
@@ -137,8 +224,10 @@ def main():
     Z = np.ascontiguousarray(Y[idx])
     torch.cuda.synchronize()
 
+    sweep = world > 1 or args.sweep
+
     def one_fit(step):
-        ls, gamma = CV_GRID[(rank + world * step) % len(CV_GRID)] if world > 1 else (20.0, 1e-6)
+        ls, gamma = CV_GRID[(rank + world * step) % len(CV_GRID)] if sweep else (20.0, 1e-6)
         reg = nk.KoopmanNystromRegressor(p, kernel=nk.ThreeDimensionalKernel(ls, ls, ls, d), gamma=gamma, m=m)
         reg.nystrom_centers_output = Z.T
         reg.fit(Xd, Yd)  # device pointers: no PCIe traffic for X, Y inside the timed region
@@ -200,8 +289,9 @@ def main():
             "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "C4 synthetic cloth-sized (BASELINE.md s3): n=%d m=%d d=%d p=%d, isotropic RBF "
-                                   "l=20 gamma=1e-6 jitter=1e-6%s" % (n, m, d, p, "" if world == 1 else
-                                                                      "; per-rank CV-grid candidates l in {10,20,40} x gamma in {1e-7..1e-3}"),
+                                   "%s jitter=1e-6" % (n, m, d, p, "l=20 gamma=1e-6" if not sweep else
+                                                       "CV-grid candidates l in {10,20,40} x gamma in {1e-7..1e-3}, candidate "
+                                                       "(rank + world*step) mod 15 per step"),
                        "n": n, "m": m, "d": d, "p": p, "inputs": "HBM-resident (device pointers through the C-ABI)",
                        "outputs": "A,B,C,W copied to page-locked host arrays by asynchronous DMA that overlaps the next fit; all copies complete inside the timed region",
                        "parallelism": "1 process/GPU, independent fits per rank, RCCL all-gather of per-fit scalars",
@@ -217,8 +307,27 @@ def main():
                          "note": "algorithmic flop with SYRK symmetry exploited: (m+p)(m+p+1)n + 2m(m+p)n + m(m+1)n + 2dmn "
                                  "in one fused launch; the split-K reduce kernel is excluded from the launch time"},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            base, ref = cpu_baseline(X, Y, idx, 20.0, 1e-6, p, min(args.cpu_sample_rows, n), args.cpu_threads)
+        if world == 1 and not args.no_extras:
+            # fits/s as the reference's fit(X, Y) is called: X, Y host NumPy arrays in, operators landed in host arrays
+            # (the 620 MB upload from pageable memory is inside; never the headline `value`)
+            def host_fit():
+                reg = nk.KoopmanNystromRegressor(p, kernel=nk.ThreeDimensionalKernel(20.0, 20.0, 20.0, d), gamma=1e-6, m=m)
+                reg.nystrom_centers_output = Z.T
+                reg.fit(X, Y)
+                return reg.A, reg.B, reg.C, reg.weights
+            host_fit()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                host_fit()
+            out["value_host_inputs"] = 3 / (time.perf_counter() - t1)
+            out["cv_sweep"] = cv_sweep_rate(nk)
+        mode = "none" if args.no_cpu_baseline else args.cpu_baseline
+        if world == 1 and mode != "none":
+            base = None
+            if mode == "full":
+                base = cpu_baseline_full(X, Y, idx, 20.0, 1e-6, p, args.cpu_threads)
+            if base is None:
+                base = cpu_baseline_sample(X, Y, idx, 20.0, 1e-6, p, min(args.cpu_sample_rows, n), args.cpu_threads)
             out["cpu_baseline"] = base
             out["gpu_over_cpu"] = value / base["value"]
         print(json.dumps(out), flush=True)

@@ -108,6 +108,41 @@ int nk_set_strict_spd(nk_ctx* ctx, int strict);
  * implicitly.  Results are complete when a call returns (every entry point synchronises its streams before returning
  * unless documented otherwise), so no ordering is needed in the other direction. */
 int nk_wait_stream(nk_ctx* ctx, void* producer_stream);
+/* ---- lock-step groups: batched execution of many SMALL fits (the (candidate, fold) units of the hyper-parameter sweep,
+ * benchmark_lqr_cloth.py:39-66; multi-seed sweeps :168-203).  One small fit is a chain of a few hundred launch-bound
+ * kernels that leaves the chip idle; a group runs `size` of them in lock step.  nk_group_create returns `size` member
+ * contexts; each is driven by its own host thread through the ordinary entry points (nk_nystrom_fit,
+ * nk_score_neg_rmse, ...).  Inside the library a member's launches are recorded, and whenever members wait for the
+ * device the recorded sequences are merged -- equal launches become one launch with blockIdx.z = member -- and issued
+ * on one shared stream.  Results are bit-identical to an ordinary context (same kernels, same arguments).
+ * nk_group_enter / nk_group_leave bracket a unit of work of one member: members inside a unit wait for one another at
+ * their synchronisation points; a member outside a unit never blocks the others (its calls still work, unbatched).
+ * Enter all members that take part in a round before any of them starts (any thread may call nk_group_enter).
+ * Destroy the members with nk_destroy; the group goes with its last member.
+ * nk_group_stats: {flushes, merged launches, single launches, member-launches covered by merged launches}. */
+int nk_group_create(int device, int size, nk_ctx** members);
+/* ---- the hyper-parameter sweep as ONE call: replaces the fit/predict/score loop GridSearchCV runs over (candidate, fold)
+ *   units (benchmark_lqr_cloth.py:52-65 and the classic / hjb twins; sklearn: clone -> fit(X_train, Y_train) ->
+ *   'neg_root_mean_squared_error' on the held-out fold).  Unit u fits on all rows of X, Y except [test_begin, test_end)
+ *   with the landmarks Y[landmark_rows[0..m)] (rows of the DATA SET, i.e. after mapping training-row indices past the
+ *   fold) and scores the held-out rows.  `members`: the contexts of ONE lock-step group (nk_group_create); the units are
+ *   run n_members at a time, one host thread per member inside the library, their kernel launches merged.
+ *   X: n x (d+p), Y: n x d (host or device).  scores[u] = the unit's score; status[u] = NK_OK or the error code of a
+ *   unit whose fit failed (its score is NaN, like GridSearchCV's error_score=nan). ------------------------------------ */
+typedef struct nk_cv_unit {
+  const nk_kernel_desc* kernel;
+  double gamma;
+  double jitter;
+  int32_t m;
+  int32_t reserved;
+  int64_t test_begin, test_end;
+  const int64_t* landmark_rows; /* m row indices into Y */
+} nk_cv_unit;
+int nk_cv_grid(nk_ctx* const* members, int32_t n_members, const double* X, int64_t ldx, const double* Y, int64_t ldy,
+               int64_t n, int32_t d, int32_t p, const nk_cv_unit* units, int32_t n_units, double* scores, int32_t* status);
+int nk_group_enter(nk_ctx* member);
+int nk_group_leave(nk_ctx* member);
+int nk_group_stats(nk_ctx* member, uint64_t* out4);
 /* Releases everything the library still holds on every device -- live contexts (their streams, events and workspaces),
  * live models, the model-buffer pool and page-locked host blocks -- after waiting for pending work.  Handles that were
  * live become invalid; destroying them afterwards is a harmless no-op, so language bindings may call this from an

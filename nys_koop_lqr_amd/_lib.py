@@ -26,6 +26,12 @@ class KernelDesc(C.Structure):
                 ("lengthscale", C.POINTER(C.c_double)), ("sigma0", C.c_double)]
 
 
+class CvUnit(C.Structure):
+    _fields_ = [("kernel", C.POINTER(KernelDesc)), ("gamma", C.c_double), ("jitter", C.c_double), ("m", C.c_int32),
+                ("reserved", C.c_int32), ("test_begin", C.c_int64), ("test_end", C.c_int64),
+                ("landmark_rows", C.POINTER(C.c_int64))]
+
+
 class FitStats(C.Structure):
     _fields_ = [("ms_total", C.c_double), ("ms_upload", C.c_double), ("ms_kmat", C.c_double),
                 ("ms_gram", C.c_double), ("ms_sqrt", C.c_double), ("ms_solve", C.c_double),
@@ -55,6 +61,12 @@ SIGNATURES = {
     "nk_set_strict_spd": (C.c_int, [_P, C.c_int]),
     "nk_wait_stream": (C.c_int, [_P, _P]),
     "nk_shutdown": (C.c_int, []),
+    "nk_group_create": (C.c_int, [C.c_int, C.c_int, C.POINTER(_P)]),
+    "nk_group_enter": (C.c_int, [_P]),
+    "nk_group_leave": (C.c_int, [_P]),
+    "nk_group_stats": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
+    "nk_cv_grid": (C.c_int, [C.POINTER(_P), _I32, _P, _I64, _P, _I64, _I64, _I32, _I32, C.POINTER(CvUnit), _I32,
+                             C.POINTER(_D), C.POINTER(_I32)]),
     "nk_host_alloc": (_P, [C.c_uint64]),
     "nk_host_free": (None, [_P]),
     "nk_kernel_matrix": (C.c_int, [_P, C.POINTER(KernelDesc), _P, _I64, _I64, _P, _I64, _I64, _P, _I64]),
@@ -137,8 +149,12 @@ def shutdown():
     with _pools_lock:
         pools = list(_pools.values())
         _pools.clear()
+        lpools = list(_lockstep_pools.values())
+        _lockstep_pools.clear()
     for pool in pools:  # worker threads hold contexts in thread-local storage; stop them before their streams go away
         pool.shutdown(wait=True)
+    for pool in lpools:
+        pool.close()
     _PinnedBlock.drain()
     lib.nk_shutdown()
 
@@ -180,12 +196,20 @@ class Mat:
 class Context:
     """One nk_ctx (HIP stream + HBM workspace) on one device.  Not thread-safe; one per process and device."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, handle=None):
         self.lib = load_library()
-        h = _P()
-        check(self.lib.nk_create(int(device), C.byref(h)))
-        self.handle = h
+        if handle is None:
+            handle = _P()
+            check(self.lib.nk_create(int(device), C.byref(handle)))
+        self.handle = handle
         self.device = int(device)
+
+    def enter(self):
+        """Lock-step group member: start of a unit of work (nk_group_enter)."""
+        check(self.lib.nk_group_enter(self.handle))
+
+    def leave(self):
+        check(self.lib.nk_group_leave(self.handle))
 
     def close(self):
         if getattr(self, "handle", None):
@@ -300,6 +324,133 @@ def get_context(device=None):
     if ctx is None:
         ctx = ctxs[key] = Context(device)
     return ctx
+
+
+class LockstepPool:
+    """`size` host threads, thread i permanently bound to member i of a lock-step group (nk_group_create): the units of a
+    round run through the ordinary API, one per thread, and the library merges their kernel launches (see
+    include/nyskoop.h).  run_round(fn, items) runs fn(item) for up to `size` items, one per member, and returns the results
+    in order; an exception in a unit is re-raised after the round."""
+
+    def __init__(self, size, device=None):
+        import queue
+        self.size = int(size)
+        self.device = default_device() if device is None else int(device)
+        lib = load_library()
+        handles = (_P * self.size)()
+        check(lib.nk_group_create(self.device, self.size, handles))
+        self.members = [Context(self.device, _P(handles[i])) for i in range(self.size)]
+        self._queues = [queue.Queue() for _ in range(self.size)]
+        self._done = queue.Queue()
+        self._threads = [threading.Thread(target=self._worker, args=(i,), daemon=True, name=f"nyskoop-lockstep-{i}")
+                         for i in range(self.size)]
+        for t in self._threads:
+            t.start()
+
+    def _worker(self, i):
+        member = self.members[i]
+        _tls.ctxs = {(os.getpid(), self.device): member}
+        while True:
+            task = self._queues[i].get()
+            if task is None:
+                return
+            fn, item, k = task
+            try:
+                out = (k, fn(item), None)
+            except BaseException as e:  # noqa: BLE001 -- reported to the caller of run_round
+                out = (k, None, e)
+            finally:
+                try:
+                    member.leave()
+                except Exception:
+                    pass
+            self._done.put(out)
+
+    def run_round(self, fn, items):
+        items = list(items)
+        if len(items) > self.size:
+            raise ValueError("more items than members")
+        for k in range(len(items)):  # all members of the round are inside their unit before any of them starts
+            self.members[k].enter()
+        for k, item in enumerate(items):
+            self._queues[k].put((fn, item, k))
+        results, err = [None] * len(items), None
+        for _ in items:
+            k, out, e = self._done.get()
+            results[k] = out
+            err = err or e
+        if err is not None:
+            raise err
+        return results
+
+    def map(self, fn, items):
+        items = list(items)
+        out = []
+        for r in range(0, len(items), self.size):
+            out.extend(self.run_round(fn, items[r:r + self.size]))
+        return out
+
+    def cv_grid(self, X, Y, n_inputs, units):
+        """nk_cv_grid: `units` = list of (DeviceKernel, gamma, jitter, m, (test_begin, test_end), landmark_rows) run in
+        lock step, len(members) at a time, entirely inside the library (no Python per unit).  Returns (scores, status)."""
+        Xm, Ym = Mat(X), Mat(Y)
+        n, d = Ym.shape
+        p = int(n_inputs)
+        if Xm.shape != (n, d + p):
+            raise ValueError(f"X has shape {Xm.shape}, expected {(n, d + p)}")
+        arr = (CvUnit * len(units))()
+        keep = []
+        descs = {}
+        for i, (kern, gamma, jitter, m, (lo, hi), rows) in enumerate(units):
+            if id(kern) not in descs:
+                descs[id(kern)] = kern.desc(d)
+            kd, ls = descs[id(kern)]
+            rows = np.ascontiguousarray(rows, dtype=np.int64)
+            if rows.shape != (int(m),):
+                raise ValueError("landmark_rows must hold m row indices")
+            keep.append(rows)
+            arr[i].kernel = C.pointer(kd)
+            arr[i].gamma, arr[i].jitter, arr[i].m = float(gamma), float(jitter), int(m)
+            arr[i].test_begin, arr[i].test_end = int(lo), int(hi)
+            arr[i].landmark_rows = rows.ctypes.data_as(C.POINTER(C.c_int64))
+        handles = (_P * self.size)(*[m_.handle for m_ in self.members])
+        scores = np.full(len(units), np.nan)
+        status = np.zeros(len(units), dtype=np.int32)
+        lib = self.members[0].lib
+        rc = lib.nk_cv_grid(handles, self.size, Xm.ptr, Xm.ld, Ym.ptr, Ym.ld, n, d, p, arr, len(units),
+                            scores.ctypes.data_as(C.POINTER(_D)), status.ctypes.data_as(C.POINTER(_I32)))
+        if rc == -1:
+            raise ValueError(lib.nk_last_error().decode())
+        check(rc)
+        return scores, status
+
+    def stats(self):
+        v = (C.c_uint64 * 4)()
+        check(self.members[0].lib.nk_group_stats(self.members[0].handle, v))
+        return dict(flushes=int(v[0]), merged_launches=int(v[1]), single_launches=int(v[2]), member_launches_merged=int(v[3]))
+
+    def close(self):
+        for q in self._queues:
+            q.put(None)
+        for t in self._threads:
+            t.join(timeout=5)
+        for m in self.members:
+            m.close()
+
+
+_lockstep_pools = {}
+
+
+def lockstep_pool(size, device=None, index=0):
+    """A persistent LockstepPool of `size` members on `device` (created on first use); `index` distinguishes several
+    pools of the same size (independent groups whose work overlaps on the GPU)."""
+    device = default_device() if device is None else int(device)
+    with _pools_lock:
+        key = (os.getpid(), device, int(size), int(index))
+        pool = _lockstep_pools.get(key)
+        if pool is None:
+            pool = _lockstep_pools[key] = LockstepPool(size, device)
+        return pool
 
 
 _pools = {}

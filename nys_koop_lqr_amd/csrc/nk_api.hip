@@ -9,8 +9,10 @@
 #include <chrono>
 #include <cstdlib>
 #include <algorithm>
+#include <condition_variable>
 #include <mutex>
 #include <set>
+#include <thread>
 
 namespace nk {
 
@@ -180,6 +182,7 @@ static int check_ctx(nk_ctx* ctx) {
     set_error("null context");
     return NK_ERR_BAD_ARG;
   }
+  tl_ctx = ctx;  // the calling thread's current context (a context is used by one thread at a time)
   NK_HIP(hipSetDevice(ctx->device));
   return arena_reset(ctx);
 }
@@ -235,7 +238,7 @@ static double* pool_take(int device, size_t bytes) {
 static void pool_give(int device, size_t bytes, double* ptr) {
   {
     std::lock_guard<std::mutex> lk(g_pool_mu);
-    if (g_pool.size() < 8) {
+    if (g_pool.size() < 512) {  // a lock-step group keeps one model per member in flight
       g_pool.push_back(ModelBuf{device, bytes, ptr});
       return;
     }
@@ -424,6 +427,8 @@ int nk_create(int device, nk_ctx** out) {
 
 static void destroy_ctx_unregistered(nk_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
+  if (tl_ctx == ctx) tl_ctx = nullptr;
+  group_detach(ctx);  // flushes what the member recorded; the group goes with its last member
   (void)hipStreamSynchronize(ctx->stream_main);
   (void)hipStreamSynchronize(ctx->stream_side);
   (void)hipStreamSynchronize(ctx->stream_prep);
@@ -470,6 +475,7 @@ static void destroy_model_unregistered(nk_model* model, bool to_pool) {
 }
 
 int nk_shutdown(void) {
+  tl_ctx = nullptr;
   std::set<nk_ctx*> ctxs;
   std::set<nk_model*> models;
   std::set<void*> blocks;
@@ -502,6 +508,11 @@ int nk_set_strict_spd(nk_ctx* ctx, int strict) {
 int nk_wait_stream(nk_ctx* ctx, void* producer_stream) {
   NK_REQUIRE(ctx != nullptr, "nk_wait_stream: null context");
   NK_HIP(hipSetDevice(ctx->device));
+  if (ctx->group) {  // the group's shared stream is fed at flush time: wait for the producer here, once
+    hipError_t e = real_stream_sync(reinterpret_cast<hipStream_t>(producer_stream));
+    if (e != hipSuccess) { set_error("synchronising the producer stream failed: %s", hipGetErrorString(e)); return NK_ERR_HIP; }
+    return NK_OK;
+  }
   NK_HIP(hipEventRecord(ctx->ev_ext, reinterpret_cast<hipStream_t>(producer_stream)));
   NK_HIP(hipStreamWaitEvent(ctx->stream_main, ctx->ev_ext, 0));
   NK_HIP(hipStreamWaitEvent(ctx->stream_side, ctx->ev_ext, 0));
@@ -510,8 +521,140 @@ int nk_wait_stream(nk_ctx* ctx, void* producer_stream) {
   return NK_OK;
 }
 
+int nk_group_create(int device, int size, nk_ctx** out) {
+  NK_REQUIRE(out != nullptr && size >= 1 && size <= 256, "nk_group_create: bad argument");
+  for (int i = 0; i < size; ++i) out[i] = nullptr;
+  for (int i = 0; i < size; ++i) {
+    int rc = nk_create(device, &out[i]);
+    if (rc != NK_OK) {
+      for (int j = 0; j < i; ++j) { nk_destroy(out[j]); out[j] = nullptr; }
+      return rc;
+    }
+  }
+  nk_group* g = group_new(device, size);
+  if (!g) {
+    for (int i = 0; i < size; ++i) { nk_destroy(out[i]); out[i] = nullptr; }
+    set_error("nk_group_create: could not create the shared stream / argument table");
+    return NK_ERR_HIP;
+  }
+  for (int i = 0; i < size; ++i) group_attach(g, i, out[i]);
+  return NK_OK;
+}
+
+int nk_group_enter(nk_ctx* ctx) {
+  NK_REQUIRE(ctx != nullptr, "nk_group_enter: null context");
+  return group_enter(ctx);
+}
+
+int nk_group_leave(nk_ctx* ctx) {
+  NK_REQUIRE(ctx != nullptr, "nk_group_leave: null context");
+  tl_ctx = ctx;
+  return group_leave(ctx);
+}
+
+int nk_group_stats(nk_ctx* ctx, uint64_t* out4) {
+  NK_REQUIRE(ctx != nullptr && out4 != nullptr, "nk_group_stats: null argument");
+  group_stats(ctx, out4);
+  return NK_OK;
+}
+
+int nk_cv_grid(nk_ctx* const* members, int32_t n_members, const double* X, int64_t ldx, const double* Y, int64_t ldy,
+               int64_t n, int32_t d, int32_t p, const nk_cv_unit* units, int32_t n_units, double* scores, int32_t* status) {
+  NK_REQUIRE(members && n_members >= 1 && X && Y && units && scores, "nk_cv_grid: null argument");
+  NK_REQUIRE(n > 0 && d > 0 && p >= 0 && n_units >= 0 && ldx >= d + p && ldy >= d, "nk_cv_grid: bad sizes");
+  for (int k = 0; k < n_members; ++k) NK_REQUIRE(members[k] != nullptr, "nk_cv_grid: null member context");
+  for (int u = 0; u < n_units; ++u) {
+    const nk_cv_unit& cu = units[u];
+    NK_REQUIRE(cu.kernel && cu.landmark_rows && cu.m > 0, "nk_cv_grid: unit %d: null kernel / landmarks", u);
+    NK_REQUIRE(0 <= cu.test_begin && cu.test_begin < cu.test_end && cu.test_end <= n, "nk_cv_grid: unit %d: bad test fold", u);
+    for (int j = 0; j < cu.m; ++j)
+      NK_REQUIRE(cu.landmark_rows[j] >= 0 && cu.landmark_rows[j] < n, "nk_cv_grid: unit %d: landmark row out of range", u);
+  }
+  if (n_units == 0) return NK_OK;
+  nk_ctx* lead = members[0];
+  NK_HIP(hipSetDevice(lead->device));
+  // the data set lives in HBM once for all units
+  const double *Xd = X, *Yd = Y;
+  int64_t ldxd = ldx, ldyd = ldy;
+  double *Xown = nullptr, *Yown = nullptr;
+  struct Free { double*& a; double*& b; ~Free() { if (a) (void)hipFree(a); if (b) (void)hipFree(b); } } freer{Xown, Yown};
+  if (!is_device_ptr(X)) {
+    ldxd = d + p + ((d + p) & 1);
+    NK_HIP(hipMalloc(reinterpret_cast<void**>(&Xown), (size_t)n * ldxd * 8));
+    NK_HIP(hipMemcpy2D(Xown, (size_t)ldxd * 8, X, (size_t)ldx * 8, (size_t)(d + p) * 8, (size_t)n, hipMemcpyHostToDevice));
+    Xd = Xown;
+  }
+  if (!is_device_ptr(Y)) {
+    ldyd = d + (d & 1);
+    NK_HIP(hipMalloc(reinterpret_cast<void**>(&Yown), (size_t)n * ldyd * 8));
+    NK_HIP(hipMemcpy2D(Yown, (size_t)ldyd * 8, Y, (size_t)ldy * 8, (size_t)d * 8, (size_t)n, hipMemcpyHostToDevice));
+    Yd = Yown;
+  }
+  // landmark rows are gathered on the host from a host copy of Y (one download if Y came as a device pointer)
+  std::vector<double> Yhost;
+  const double* Yh = Y;
+  int64_t ldyh = ldy;
+  if (is_device_ptr(Y)) {
+    Yhost.resize((size_t)n * d);
+    NK_HIP(hipMemcpy2D(Yhost.data(), (size_t)d * 8, Y, (size_t)ldy * 8, (size_t)d * 8, (size_t)n, hipMemcpyDeviceToHost));
+    Yh = Yhost.data();
+    ldyh = d;
+  }
+  const int B = n_members;
+  // one host thread per member; rounds of B units; everybody is inside its unit before anybody starts (round barrier)
+  struct Round {
+    std::mutex mu;
+    std::condition_variable cv;
+    int arrived = 0;
+    uint64_t gen = 0;
+    void wait(int parties) {
+      std::unique_lock<std::mutex> lk(mu);
+      const uint64_t g = gen;
+      if (++arrived == parties) { arrived = 0; ++gen; lk.unlock(); cv.notify_all(); return; }
+      cv.wait(lk, [&] { return gen != g; });
+    }
+  } round;
+  const int n_rounds = (n_units + B - 1) / B;
+  auto worker = [&](int k) {
+    nk_ctx* ctx = members[k];
+    std::vector<double> Z;
+    for (int r = 0; r < n_rounds; ++r) {
+      const int u = r * B + k;
+      const bool mine = u < n_units;
+      if (mine) (void)group_enter(ctx);
+      round.wait(B);
+      if (mine) {
+        const nk_cv_unit& cu = units[u];
+        Z.resize((size_t)cu.m * d);
+        for (int j = 0; j < cu.m; ++j) memcpy(&Z[(size_t)j * d], Yh + cu.landmark_rows[j] * ldyh, (size_t)d * 8);
+        const int64_t rr[4] = {0, cu.test_begin, cu.test_end, n};
+        nk_model* mdl = nullptr;
+        int rc = nk_nystrom_fit(ctx, cu.kernel, Xd, ldxd, Yd, ldyd, n, d, p, rr, 2, nullptr, 0, Z.data(), d, cu.m, cu.gamma,
+                                cu.jitter, &mdl, nullptr);
+        double sc = std::nan("");
+        if (rc == NK_OK)
+          rc = nk_score_neg_rmse(ctx, mdl, Xd + cu.test_begin * ldxd, ldxd, Yd + cu.test_begin * ldyd, ldyd,
+                                 cu.test_end - cu.test_begin, &sc);
+        if (mdl) nk_model_destroy(mdl);
+        scores[u] = rc == NK_OK ? sc : std::nan("");
+        if (status) status[u] = rc;
+        tl_ctx = ctx;
+        (void)group_leave(ctx);
+      }
+      round.wait(B);
+    }
+    tl_ctx = nullptr;
+  };
+  std::vector<std::thread> threads;
+  threads.reserve((size_t)B);
+  for (int k = 0; k < B; ++k) threads.emplace_back(worker, k);
+  for (auto& t : threads) t.join();
+  return NK_OK;
+}
+
 int nk_synchronize(nk_ctx* ctx) {
   NK_REQUIRE(ctx != nullptr, "null context");
+  tl_ctx = ctx;
   NK_HIP(hipStreamSynchronize(ctx->stream));
   return NK_OK;
 }
@@ -636,6 +779,24 @@ static int fit_impl(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int6
   if (mode != FIT_SOLVE) {
     NK_TRY(stage_in(ctx, X, ldx, n, d + p, &x));
     NK_TRY(stage_in(ctx, Y, ldy, n, d, &y));
+  }
+  if (mode != FIT_SOLVE && rng.size() > 2 && (double)n_eff * (2.0 * d + p) * 8.0 <= 256e6) {
+    // several row ranges (a K-fold training set is two): gather the rows into contiguous scratch once, so that everything
+    // downstream sees ONE piece of n_eff rows whatever the split point -- the kernel blocks and the fused Gram launch then
+    // have the same shape for every fold (which is also what lets the units of a sweep share launches, nk_lockstep.h)
+    const int64_t ldxg = (d + p + 1) & ~(int64_t)1, ldyg = (d + 1) & ~(int64_t)1;
+    double *xg = nullptr, *yg = nullptr;
+    NK_TRY(arena_alloc_t(ctx, (size_t)n_eff * ldxg, &xg));
+    NK_TRY(arena_alloc_t(ctx, (size_t)n_eff * ldyg, &yg));
+    int64_t o = 0;
+    for (size_t i = 0; i < rng.size(); i += 2) {
+      const int64_t b = rng[i], len = rng[i + 1] - rng[i];
+      NK_TRY(launch_copy2d(ctx, x.ptr + b * x.ld, x.ld, xg + o * ldxg, ldxg, len, d + p));
+      NK_TRY(launch_copy2d(ctx, y.ptr + b * y.ld, y.ld, yg + o * ldyg, ldyg, len, d));
+      o += len;
+    }
+    x.ptr = xg; x.ld = ldxg; y.ptr = yg; y.ld = ldyg;
+    rng.assign({(int64_t)0, n_eff});
   }
   NK_TRY(stage_in(ctx, Zout, ldzo, m, d, &zo));
   if (same_centers) zi = zo; else NK_TRY(stage_in(ctx, Zin, ldzi, m, d, &zi));

@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "nyskoop.h"
+#include "nk_lockstep.h"
 
 namespace nk {
 
@@ -54,6 +55,7 @@ struct ArenaMark {
 
 }  // namespace nk
 
+struct nk_member_state;
 struct nk_ctx {
   int device = 0;
   hipStream_t stream = nullptr;       // CURRENT stream: every launcher uses this (swapped by nk::SideScope)
@@ -80,6 +82,8 @@ struct nk_ctx {
   int strict_spd = 0; // 1: a non-positive Cholesky pivot is an error (NK_ERR_NOT_SPD) instead of entering the
                       // rank-truncating pseudo-inverse path (NYSKOOP_STRICT_SPD=1 / nk_set_strict_spd)
   hipEvent_t ev_ext = nullptr;  // ordering against a caller's stream (nk_wait_stream)
+  nk_group* group = nullptr;    // member of a lock-step group (nk_lockstep.h): stream operations are recorded and merged
+  nk_member_state* gstate = nullptr;
   double* h_stage = nullptr;    // page-locked, device-visible staging block for the small latency-bound calls (rollouts):
   size_t h_stage_bytes = 0;     // kernels read their inputs from it and write their results into it directly (no DMA)
 };
@@ -119,6 +123,15 @@ struct SideScope {
 // factorisation failure flags: slots 0-1 belong to the main stream, 2-3 to the side stream (each stream may have a paired
 // factorisation in flight)
 inline int info_base(const nk_ctx* c) { return c->stream != c->stream_main ? 2 : 0; }
+
+// ---- lock-step groups (nk_group.hip) ----------------------------------------------------------------------------
+nk_group* group_new(int device, int size);
+void group_attach(nk_group* g, int slot, nk_ctx* c);
+void group_detach(nk_ctx* c);
+int group_enter(nk_ctx* c);
+int group_leave(nk_ctx* c);
+void group_stats(nk_ctx* c, uint64_t out[4]);
+hipError_t real_stream_sync(hipStream_t s);
 
 // ---- workspace -------------------------------------------------------------------------------------------
 int arena_reset(nk_ctx* ctx);

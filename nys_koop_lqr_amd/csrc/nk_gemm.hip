@@ -140,7 +140,7 @@ __device__ __forceinline__ void store_transposing(double* __restrict__ S, const 
 }
 
 template <bool TA, bool TB>
-__global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_f64_kernel(GemmBatch batch) {
+__device__ __forceinline__ void gemm_f64_body(const GemmBatch& batch) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const GemmParams& p = batch.p[blockIdx.y];  // blockIdx.y selects the problem of a batched launch
   if ((int)blockIdx.x >= p.nblocks) return;
@@ -247,11 +247,21 @@ __global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_f64_kernel(GemmBatch bat
         }
   }
 }
+template <bool TA, bool TB>
+__global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_f64_kernel(GemmBatch batch) { gemm_f64_body<TA, TB>(batch); }
+template <bool TA, bool TB>
+__global__ void __launch_bounds__(GEMM_THREADS, 2) gemm_f64_kernel_batched(const nk::ArgPack<GemmBatch>* table) {
+  gemm_f64_body<TA, TB>(table[blockIdx.z].v);
+}
+#define NK_GEMM_TWIN(A, B, tag)                                                                                       \
+  static nk::TwinReg gemm_twin_reg_##tag(reinterpret_cast<const void*>(static_cast<void (*)(GemmBatch)>(gemm_f64_kernel<A, B>)), \
+                                         reinterpret_cast<const void*>(gemm_f64_kernel_batched<A, B>),                  \
+                                         sizeof(nk::ArgPack<GemmBatch>), "gemm_f64_kernel_" #tag);
+NK_GEMM_TWIN(false, false, nn) NK_GEMM_TWIN(false, true, nt) NK_GEMM_TWIN(true, false, tn) NK_GEMM_TWIN(true, true, tt)
+
 
 // C = alpha * sum_s slab[s] + beta * C, honouring the triangular tile modes.
-__global__ void __launch_bounds__(256) gemm_reduce_kernel(const double* __restrict__ slab, int splitk, int M, int N,
-                                                          double alpha, double beta, double* __restrict__ C,
-                                                          int64_t ldc, int tri) {
+__device__ __forceinline__ void gemm_reduce_kernel_body(const double* __restrict__ slab, int splitk, int M, int N, double alpha, double beta, double* __restrict__ C, int64_t ldc, int tri) {
   const int64_t total = (int64_t)M * N;
   for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
     const int row = (int)(e / N), col = (int)(e - (int64_t)row * N);
@@ -266,6 +276,8 @@ __global__ void __launch_bounds__(256) gemm_reduce_kernel(const double* __restri
     if (tri == TRI_UPPER_MIRROR && tr != tc) C[(int64_t)col * ldc + row] = v;
   }
 }
+__global__ void __launch_bounds__(256) gemm_reduce_kernel(const double* __restrict__ slab, int splitk, int M, int N, double alpha, double beta, double* __restrict__ C, int64_t ldc, int tri) { gemm_reduce_kernel_body(slab, splitk, M, N, alpha, beta, C, ldc, tri); }
+NK_BATCHED_TWIN(gemm_reduce_kernel, (256), const double*, int, int, int, double, double, double*, int64_t, int)
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
@@ -317,6 +329,14 @@ static int gemm_set_attrs() {
                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f64_kernel<true, false>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f64_kernel_batched<false, false>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f64_kernel_batched<false, true>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f64_kernel_batched<true, false>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+    NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f64_kernel_batched<true, true>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f64_kernel<true, true>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     attr_set = true;
@@ -359,10 +379,46 @@ int launch_gemm_pair(nk_ctx* ctx, bool transA, bool transB, const GemmCall* call
   return NK_OK;
 }
 
+// Small products (lift of a few states, the product with C after a rollout, p-column blocks): the 128 x 128 engine
+// would put the whole problem on one or two CUs and take 20-30 us; here every 16 x 16 output tile is a workgroup, operands
+// addressed through (row, column) strides so that one kernel serves all four transposition cases.
+__device__ __forceinline__ void gemm_small_kernel_body(int M, int N, int K, double alpha, const double* __restrict__ A, int64_t sai, int64_t sak, const double* __restrict__ B, int64_t sbk, int64_t sbj, double beta, double* __restrict__ C, int64_t ldc) {
+  __shared__ double As[16][17];
+  __shared__ double Bs[16][17];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int i0 = blockIdx.y * 16, j0 = blockIdx.x * 16;
+  double acc = 0.0;
+  for (int k0 = 0; k0 < K; k0 += 16) {
+    const int ia = i0 + ty, ka = k0 + tx;
+    As[ty][tx] = (ia < M && ka < K) ? A[(int64_t)ia * sai + (int64_t)ka * sak] : 0.0;
+    const int kb = k0 + ty, jb = j0 + tx;
+    Bs[ty][tx] = (kb < K && jb < N) ? B[(int64_t)kb * sbk + (int64_t)jb * sbj] : 0.0;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc = fma(As[ty][k], Bs[k][tx], acc);
+    __syncthreads();
+  }
+  const int i = i0 + ty, j = j0 + tx;
+  if (i < M && j < N) {
+    double* c = C + (int64_t)i * ldc + j;
+    *c = (beta == 0.0) ? alpha * acc : fma(alpha, acc, beta * *c);
+  }
+}
+__global__ void __launch_bounds__(256) gemm_small_kernel(int M, int N, int K, double alpha, const double* __restrict__ A, int64_t sai, int64_t sak, const double* __restrict__ B, int64_t sbk, int64_t sbj, double beta, double* __restrict__ C, int64_t ldc) { gemm_small_kernel_body(M, N, K, alpha, A, sai, sak, B, sbk, sbj, beta, C, ldc); }
+NK_BATCHED_TWIN(gemm_small_kernel, (256), int, int, int, double, const double*, int64_t, int64_t, const double*, int64_t, int64_t, double, double*, int64_t)
+
 int launch_gemm(nk_ctx* ctx, bool transA, bool transB, int64_t M, int64_t N, int64_t K, double alpha, const double* A,
                 int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc, const GemmOpts& opts,
                 float* ms_kernel) {
   if (M <= 0 || N <= 0) return NK_OK;
+  if (opts.tri == TRI_FULL && opts.splitk == 0 && ms_kernel == nullptr && M * N <= 32768 && K <= 1024) {
+    const int64_t sai = transA ? 1 : lda, sak = transA ? lda : 1;   // A(i, k)
+    const int64_t sbk = transB ? 1 : ldb, sbj = transB ? ldb : 1;   // B(k, j)
+    hipLaunchKernelGGL(gemm_small_kernel, dim3((unsigned)((N + 15) / 16), (unsigned)((M + 15) / 16)), dim3(256), 0,
+                       ctx->stream, (int)M, (int)N, (int)K, alpha, A, sai, sak, B, sbk, sbj, beta, C, ldc);
+    NK_HIP(hipGetLastError());
+    return NK_OK;
+  }
   if (transA && !transB && opts.tri != TRI_LOWER && opts.splitk == 0 && K >= 128) {
     // contraction-major operands: LDS-DMA engine (nk_gemm_tn.hip) when the alignment contract holds
     TnProblem tp;

@@ -311,6 +311,22 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_f64_kernel(TnParams P) {
 __global__ void __launch_bounds__(256, 2) gram_fused_f64_kernel(TnParams P) {
   tn_body<0>(P);
 }
+// batched twins (nk_lockstep.h): the same body, parameters from table[blockIdx.z]
+template <int EPI>
+__global__ void __launch_bounds__(256, 2) gemm_tn_f64_kernel_batched(const nk::ArgPack<TnParams>* table) {
+  tn_body<EPI>(table[blockIdx.z].v);  // by reference: a local copy of the (dynamically indexed) struct would live in scratch
+}
+__global__ void __launch_bounds__(256, 2) gram_fused_f64_kernel_batched(const nk::ArgPack<TnParams>* table) {
+  tn_body<0>(table[blockIdx.z].v);
+}
+#define NK_TN_TWIN(E)                                                                                                   \
+  static nk::TwinReg tn_twin_reg_##E(reinterpret_cast<const void*>(static_cast<void (*)(TnParams)>(gemm_tn_f64_kernel<E>)), \
+                                     reinterpret_cast<const void*>(gemm_tn_f64_kernel_batched<E>),                        \
+                                     sizeof(nk::ArgPack<TnParams>), "gemm_tn_f64_kernel<" #E ">");
+NK_TN_TWIN(0) NK_TN_TWIN(1) NK_TN_TWIN(2) NK_TN_TWIN(3)
+static nk::TwinReg gram_fused_twin_reg(reinterpret_cast<const void*>(static_cast<void (*)(TnParams)>(gram_fused_f64_kernel)),
+                                       reinterpret_cast<const void*>(gram_fused_f64_kernel_batched),
+                                       sizeof(nk::ArgPack<TnParams>), "gram_fused_f64_kernel");
 
 struct TnRed {
   double* C;
@@ -336,7 +352,7 @@ struct TnRedParams {
 // a 16-row band of the slices in slice order (deterministic) with 16-byte loads; the mirrored / transposed copies go
 // through LDS so that their stores are 64-byte runs instead of single strided doubles.
 constexpr int RPARTS = 8;
-__global__ void __launch_bounds__(256) gemm_tn_reduce_kernel(TnRedParams P) {
+__device__ __forceinline__ void gemm_tn_reduce_kernel_body(const TnRedParams& P) {
   __shared__ double sh[16][130];
   if (P.skip_state != nullptr) {
     const double f = P.skip_state[0];
@@ -411,10 +427,16 @@ __global__ void __launch_bounds__(256) gemm_tn_reduce_kernel(TnRedParams P) {
     if (mirror && pr.Caff) pr.Caff[(int64_t)col * pr.ldc + row] = pr.aff_a * v;  // off-diagonal tile: no identity term
   }
 }
+__global__ void __launch_bounds__(256) gemm_tn_reduce_kernel(TnRedParams P) { gemm_tn_reduce_kernel_body(P); }
+__global__ void __launch_bounds__(256) gemm_tn_reduce_kernel_batched(const nk::ArgPack<TnRedParams>* table) {
+  gemm_tn_reduce_kernel_body(table[blockIdx.z].v);
+}
+static nk::TwinReg gemm_tn_reduce_twin_reg(reinterpret_cast<const void*>(static_cast<void (*)(TnRedParams)>(gemm_tn_reduce_kernel)),
+                                           reinterpret_cast<const void*>(gemm_tn_reduce_kernel_batched),
+                                           sizeof(nk::ArgPack<TnRedParams>), "gemm_tn_reduce_kernel");
 
 // 32x32 tiled transpose through LDS
-__global__ void __launch_bounds__(256) transpose_kernel(const double* __restrict__ src, int64_t lds_, double* __restrict__ dst,
-                                                        int64_t ldd, int rows, int cols) {
+__device__ __forceinline__ void transpose_kernel_body(const double* __restrict__ src, int64_t lds_, double* __restrict__ dst, int64_t ldd, int rows, int cols) {
   __shared__ double tile[32][33];
   const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -428,6 +450,8 @@ __global__ void __launch_bounds__(256) transpose_kernel(const double* __restrict
     if (orow < cols && ocol < rows) dst[(int64_t)orow * ldd + ocol] = tile[tx][r];
   }
 }
+__global__ void __launch_bounds__(256) transpose_kernel(const double* __restrict__ src, int64_t lds_, double* __restrict__ dst, int64_t ldd, int rows, int cols) { transpose_kernel_body(src, lds_, dst, ldd, rows, cols); }
+NK_BATCHED_TWIN(transpose_kernel, (256), const double*, int64_t, double*, int64_t, int, int)
 
 int launch_transpose(nk_ctx* ctx, const double* src, int64_t lds_, double* dst, int64_t ldd, int rows, int cols) {
   if (rows <= 0 || cols <= 0) return NK_OK;
@@ -536,6 +560,16 @@ int launch_gemm_tn_multi(nk_ctx* ctx, const TnProblem* probs, int nprob, int64_t
                                hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES));
     NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_f64_kernel<3>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES));
+    NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_f64_kernel_batched<0>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES));
+    NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_f64_kernel_batched<1>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES));
+    NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_f64_kernel_batched<2>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES));
+    NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_f64_kernel_batched<3>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES));
+    NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gram_fused_f64_kernel_batched),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES));
     g_tn_attr_set = true;
   }
   if (ms_kernel) NK_HIP(hipEventRecord(ctx->ev[14], ctx->stream));
@@ -566,9 +600,7 @@ int launch_gemm_tn_multi(nk_ctx* ctx, const TnProblem* probs, int nprob, int64_t
 // Error of the Gram form: |dD| <~ eps * (|a|^2 + |b|^2) absolute, i.e. a RELATIVE error of |dD|/2 on k (RBF), which the
 // centring keeps at the 1e-15 level for the shapes of SURVEY 8d.
 // ---------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) prep_rows_kernel(const double* __restrict__ X, int64_t ldx, int rows, int d,
-                                                        const double* __restrict__ winv, const double* __restrict__ center,
-                                                        double* __restrict__ Xt, int64_t ldt) {
+__device__ __forceinline__ void prep_rows_kernel_body(const double* __restrict__ X, int64_t ldx, int rows, int d, const double* __restrict__ winv, const double* __restrict__ center, double* __restrict__ Xt, int64_t ldt) {
   __shared__ double tile[32][33];
   const int k0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -582,10 +614,11 @@ __global__ void __launch_bounds__(256) prep_rows_kernel(const double* __restrict
     if (k < d && row < rows) Xt[(int64_t)k * ldt + row] = tile[tx][r];
   }
 }
+__global__ void __launch_bounds__(256) prep_rows_kernel(const double* __restrict__ X, int64_t ldx, int rows, int d, const double* __restrict__ winv, const double* __restrict__ center, double* __restrict__ Xt, int64_t ldt) { prep_rows_kernel_body(X, ldx, rows, d, winv, center, Xt, ldt); }
+NK_BATCHED_TWIN(prep_rows_kernel, (256), const double*, int64_t, int, int, const double*, const double*, double*, int64_t)
 // squared norms of the columns of Xt (d x rows): 64 columns per workgroup, the d rows dealt to the four waves
 // (coalesced 512-byte row segments, four loads in flight per lane), fixed-order sum of the four partials
-__global__ void __launch_bounds__(256) colsq_kernel(const double* __restrict__ Xt, int64_t ldt, int rows, int d,
-                                                    double* __restrict__ sq) {
+__device__ __forceinline__ void colsq_kernel_body(const double* __restrict__ Xt, int64_t ldt, int rows, int d, double* __restrict__ sq) {
   __shared__ double part[4][64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int i = blockIdx.x * 64 + lane;
@@ -606,9 +639,10 @@ __global__ void __launch_bounds__(256) colsq_kernel(const double* __restrict__ X
   __syncthreads();
   if (w == 0 && i < rows) sq[i] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
 }
+__global__ void __launch_bounds__(256) colsq_kernel(const double* __restrict__ Xt, int64_t ldt, int rows, int d, double* __restrict__ sq) { colsq_kernel_body(Xt, ldt, rows, d, sq); }
+NK_BATCHED_TWIN(colsq_kernel, (256), const double*, int64_t, int, int, double*)
 // column means in two deterministic passes: per-chunk partial sums (coalesced across columns), then a fixed-order sum
-__global__ void __launch_bounds__(256) colsum_partial_kernel(const double* __restrict__ Z, int64_t ldz, int rows, int d,
-                                                             int rows_per_chunk, double* __restrict__ partial) {
+__device__ __forceinline__ void colsum_partial_kernel_body(const double* __restrict__ Z, int64_t ldz, int rows, int d, int rows_per_chunk, double* __restrict__ partial) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= d) return;
   const int r0 = blockIdx.y * rows_per_chunk;
@@ -617,14 +651,17 @@ __global__ void __launch_bounds__(256) colsum_partial_kernel(const double* __res
   for (int r = r0; r < r1; ++r) s += Z[(int64_t)r * ldz + k];
   partial[(int64_t)blockIdx.y * d + k] = s;
 }
-__global__ void __launch_bounds__(256) colmean_finish_kernel(const double* __restrict__ partial, int chunks, int rows, int d,
-                                                             double* __restrict__ mean) {
+__global__ void __launch_bounds__(256) colsum_partial_kernel(const double* __restrict__ Z, int64_t ldz, int rows, int d, int rows_per_chunk, double* __restrict__ partial) { colsum_partial_kernel_body(Z, ldz, rows, d, rows_per_chunk, partial); }
+NK_BATCHED_TWIN(colsum_partial_kernel, (256), const double*, int64_t, int, int, int, double*)
+__device__ __forceinline__ void colmean_finish_kernel_body(const double* __restrict__ partial, int chunks, int rows, int d, double* __restrict__ mean) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= d) return;
   double s = 0.0;
   for (int c = 0; c < chunks; ++c) s += partial[(int64_t)c * d + k];
   mean[k] = s / rows;
 }
+__global__ void __launch_bounds__(256) colmean_finish_kernel(const double* __restrict__ partial, int chunks, int rows, int d, double* __restrict__ mean) { colmean_finish_kernel_body(partial, chunks, rows, d, mean); }
+NK_BATCHED_TWIN(colmean_finish_kernel, (256), const double*, int, int, int, double*)
 
 int launch_colmean(nk_ctx* ctx, const double* Z, int64_t ldz, int rows, int d, double* mean) {
   const ArenaMark mk = arena_mark(ctx);
@@ -678,6 +715,16 @@ int launch_kmat_gram(nk_ctx* ctx, int ktype, const double* At, int64_t ldat, con
     NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_f64_kernel<2>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES));
     NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_f64_kernel<3>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES));
+    NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_f64_kernel_batched<0>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES));
+    NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_f64_kernel_batched<1>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES));
+    NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_f64_kernel_batched<2>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES));
+    NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_f64_kernel_batched<3>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES));
+    NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gram_fused_f64_kernel_batched),
                                hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES));
     g_tn_attr_set = true;
   }

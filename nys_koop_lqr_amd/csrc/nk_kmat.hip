@@ -31,10 +31,7 @@ __device__ __forceinline__ double kmat_epilogue(double acc, double sigma0sq) {
 }
 
 template <int KTYPE>
-__global__ void __launch_bounds__(256, 2)
-kmat_kernel(const double* __restrict__ A, int64_t lda, int nA, const double* __restrict__ B, int64_t ldb, int nB, int d,
-            const double* __restrict__ winv, double sigma0sq, double* __restrict__ out, int64_t ldo, int vecA,
-            int vecB, int vecO) {
+__device__ __forceinline__ void kmat_body(const double* __restrict__ A, int64_t lda, int nA, const double* __restrict__ B, int64_t ldb, int nB, int d, const double* __restrict__ winv, double sigma0sq, double* __restrict__ out, int64_t ldo, int vecA, int vecB, int vecO) {
   __shared__ __attribute__((aligned(16))) double As[KBK * KSTRIDE];
   __shared__ __attribute__((aligned(16))) double Bs[KBK * KSTRIDE];
   const int tid = threadIdx.x;
@@ -124,6 +121,20 @@ kmat_kernel(const double* __restrict__ A, int64_t lda, int nA, const double* __r
     }
   }
 }
+template <int KTYPE>
+__global__ void __launch_bounds__(256, 2)
+kmat_kernel(const double* __restrict__ A, int64_t lda, int nA, const double* __restrict__ B, int64_t ldb, int nB, int d, const double* __restrict__ winv, double sigma0sq, double* __restrict__ out, int64_t ldo, int vecA, int vecB, int vecO) { kmat_body<KTYPE>(A, lda, nA, B, ldb, nB, d, winv, sigma0sq, out, ldo, vecA, vecB, vecO); }
+template <int KTYPE>
+__global__ void __launch_bounds__(256, 2) kmat_kernel_batched(const nk::ArgPack<const double*, int64_t, int, const double*, int64_t, int, int, const double*, double, double*, int64_t, int, int, int>* table) {
+  const nk::ArgPack<const double*, int64_t, int, const double*, int64_t, int, int, const double*, double, double*, int64_t, int, int, int> p = table[blockIdx.z];
+  nk::pack_apply([](auto... a) { kmat_body<KTYPE>(a...); }, p);
+}
+#define NK_KMAT_TWIN(K)                                                                                              \
+  static nk::TwinReg kmat_twin_reg_##K(                                                                              \
+      reinterpret_cast<const void*>(static_cast<void (*)(const double*, int64_t, int, const double*, int64_t, int, int, const double*, double, double*, int64_t, int, int, int)>(kmat_kernel<K>)),                                  \
+      reinterpret_cast<const void*>(kmat_kernel_batched<K>), sizeof(nk::ArgPack<const double*, int64_t, int, const double*, int64_t, int, int, const double*, double, double*, int64_t, int, int, int>), "kmat_kernel<" #K ">");
+NK_KMAT_TWIN(0) NK_KMAT_TWIN(1) NK_KMAT_TWIN(2)
+
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 

@@ -16,20 +16,22 @@ namespace nk {
 // ---------------------------------------------------------------------------------------------------------------
 // elementwise helpers
 // ---------------------------------------------------------------------------------------------------------------
-__global__ void add_diag_kernel(double* A, int64_t lda, int n, double v) {
+__device__ __forceinline__ void add_diag_kernel_body(double* A, int64_t lda, int n, double v) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) A[(int64_t)i * lda + i] += v;
 }
-__global__ void copy2d_kernel(const double* __restrict__ src, int64_t lds, double* __restrict__ dst, int64_t ldd,
-                              int64_t rows, int64_t cols) {
+__global__ void __launch_bounds__(256) add_diag_kernel(double* A, int64_t lda, int n, double v) { add_diag_kernel_body(A, lda, n, v); }
+NK_BATCHED_TWIN(add_diag_kernel, (256), double*, int64_t, int, double)
+__device__ __forceinline__ void copy2d_kernel_body(const double* __restrict__ src, int64_t lds, double* __restrict__ dst, int64_t ldd, int64_t rows, int64_t cols) {
   const int64_t total = rows * cols;
   for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
     const int64_t r = e / cols, c = e - r * cols;
     dst[r * ldd + c] = src[r * lds + c];
   }
 }
-__global__ void axpby2d_kernel(double a, const double* __restrict__ X, int64_t ldx, double b, double* __restrict__ Y,
-                               int64_t ldy, int64_t rows, int64_t cols) {
+__global__ void __launch_bounds__(256) copy2d_kernel(const double* __restrict__ src, int64_t lds, double* __restrict__ dst, int64_t ldd, int64_t rows, int64_t cols) { copy2d_kernel_body(src, lds, dst, ldd, rows, cols); }
+NK_BATCHED_TWIN(copy2d_kernel, (256), const double*, int64_t, double*, int64_t, int64_t, int64_t)
+__device__ __forceinline__ void axpby2d_kernel_body(double a, const double* __restrict__ X, int64_t ldx, double b, double* __restrict__ Y, int64_t ldy, int64_t rows, int64_t cols) {
   const int64_t total = rows * cols;
   for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
     const int64_t r = e / cols, c = e - r * cols;
@@ -37,14 +39,14 @@ __global__ void axpby2d_kernel(double a, const double* __restrict__ X, int64_t l
     Y[r * ldy + c] = a * X[r * ldx + c] + y;
   }
 }
+__global__ void __launch_bounds__(256) axpby2d_kernel(double a, const double* __restrict__ X, int64_t ldx, double b, double* __restrict__ Y, int64_t ldy, int64_t rows, int64_t cols) { axpby2d_kernel_body(a, X, ldx, b, Y, ldy, rows, cols); }
+NK_BATCHED_TWIN(axpby2d_kernel, (256), double, const double*, int64_t, double, double*, int64_t, int64_t, int64_t)
 __device__ __forceinline__ bool launch_skipped(const double* state, int step) {
   if (state == nullptr) return false;
   const double f = state[0];
   return f != 0.0 && f <= (double)step;
 }
-__global__ void scale_add_identity_kernel(double a, const double* __restrict__ X, int64_t ldx, double c,
-                                          double* __restrict__ Y, int64_t ldy, int n, const double* skip_state,
-                                          int skip_step) {
+__device__ __forceinline__ void scale_add_identity_kernel_body(double a, const double* __restrict__ X, int64_t ldx, double c, double* __restrict__ Y, int64_t ldy, int n, const double* skip_state, int skip_step) {
   if (launch_skipped(skip_state, skip_step)) return;
   const int64_t total = (int64_t)n * n;
   for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
@@ -52,13 +54,17 @@ __global__ void scale_add_identity_kernel(double a, const double* __restrict__ X
     Y[r * ldy + col] = a * X[r * ldx + col] + (r == col ? c : 0.0);
   }
 }
-__global__ void fill_kernel(double* A, int64_t lda, int64_t rows, int64_t cols, double v) {
+__global__ void __launch_bounds__(256) scale_add_identity_kernel(double a, const double* __restrict__ X, int64_t ldx, double c, double* __restrict__ Y, int64_t ldy, int n, const double* skip_state, int skip_step) { scale_add_identity_kernel_body(a, X, ldx, c, Y, ldy, n, skip_state, skip_step); }
+NK_BATCHED_TWIN(scale_add_identity_kernel, (256), double, const double*, int64_t, double, double*, int64_t, int, const double*, int)
+__device__ __forceinline__ void fill_kernel_body(double* A, int64_t lda, int64_t rows, int64_t cols, double v) {
   const int64_t total = rows * cols;
   for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
     const int64_t r = e / cols, c = e - r * cols;
     A[r * lda + c] = v;
   }
 }
+__global__ void __launch_bounds__(256) fill_kernel(double* A, int64_t lda, int64_t rows, int64_t cols, double v) { fill_kernel_body(A, lda, rows, cols, v); }
+NK_BATCHED_TWIN(fill_kernel, (256), double*, int64_t, int64_t, int64_t, double)
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -72,9 +78,7 @@ __device__ __forceinline__ double wave_max(double v) {
 }
 
 // per-block partial sums of (M - I)^2; finished by a second single-block pass (deterministic order)
-__global__ void __launch_bounds__(256) frob_mi_partial_kernel(const double* __restrict__ M, int64_t ldm, int n,
-                                                              double* __restrict__ partial, const double* skip_state,
-                                                              int skip_step) {
+__device__ __forceinline__ void frob_mi_partial_kernel_body(const double* __restrict__ M, int64_t ldm, int n, double* __restrict__ partial, const double* skip_state, int skip_step) {
   if (launch_skipped(skip_state, skip_step)) return;  // the stale partials give the old residual: harmless
   __shared__ double sh[4];
   const int64_t total = (int64_t)n * n;
@@ -89,9 +93,10 @@ __global__ void __launch_bounds__(256) frob_mi_partial_kernel(const double* __re
   __syncthreads();
   if (threadIdx.x == 0) partial[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
 }
+__global__ void __launch_bounds__(256) frob_mi_partial_kernel(const double* __restrict__ M, int64_t ldm, int n, double* __restrict__ partial, const double* skip_state, int skip_step) { frob_mi_partial_kernel_body(M, ldm, n, partial, skip_state, skip_step); }
+NK_BATCHED_TWIN(frob_mi_partial_kernel, (256), const double*, int64_t, int, double*, const double*, int)
 // per-block partial [sum of squares, trace]; finished by sum_partials_kernel on each half
-__global__ void __launch_bounds__(256) sumsq_trace_partial_kernel(const double* __restrict__ M, int64_t ldm, int n,
-                                                                  double* __restrict__ partial, int nblocks) {
+__device__ __forceinline__ void sumsq_trace_partial_kernel_body(const double* __restrict__ M, int64_t ldm, int n, double* __restrict__ partial, int nblocks) {
   __shared__ double sh[8];
   const int64_t total = (int64_t)n * n;
   double s = 0.0, t = 0.0;
@@ -110,8 +115,9 @@ __global__ void __launch_bounds__(256) sumsq_trace_partial_kernel(const double* 
     partial[nblocks + blockIdx.x] = sh[4] + sh[5] + sh[6] + sh[7];
   }
 }
-__global__ void __launch_bounds__(256) sum_partials_kernel(const double* __restrict__ partial, int count,
-                                                           double* __restrict__ out) {
+__global__ void __launch_bounds__(256) sumsq_trace_partial_kernel(const double* __restrict__ M, int64_t ldm, int n, double* __restrict__ partial, int nblocks) { sumsq_trace_partial_kernel_body(M, ldm, n, partial, nblocks); }
+NK_BATCHED_TWIN(sumsq_trace_partial_kernel, (256), const double*, int64_t, int, double*, int)
+__device__ __forceinline__ void sum_partials_kernel_body(const double* __restrict__ partial, int count, double* __restrict__ out) {
   __shared__ double sh[4];
   double s = 0.0;
   for (int i = threadIdx.x; i < count; i += blockDim.x) s += partial[i];
@@ -120,9 +126,10 @@ __global__ void __launch_bounds__(256) sum_partials_kernel(const double* __restr
   __syncthreads();
   if (threadIdx.x == 0) out[0] = sh[0] + sh[1] + sh[2] + sh[3];
 }
+__global__ void __launch_bounds__(256) sum_partials_kernel(const double* __restrict__ partial, int count, double* __restrict__ out) { sum_partials_kernel_body(partial, count, out); }
+NK_BATCHED_TWIN(sum_partials_kernel, (256), const double*, int, double*)
 // one wave per row: |row| sums, then max over rows via a second pass
-__global__ void __launch_bounds__(256) abs_rowsum_kernel(const double* __restrict__ M, int64_t ldm, int n,
-                                                         double* __restrict__ rowsum) {
+__device__ __forceinline__ void abs_rowsum_kernel_body(const double* __restrict__ M, int64_t ldm, int n, double* __restrict__ rowsum) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= n) return;
   double s = 0.0;
@@ -130,7 +137,9 @@ __global__ void __launch_bounds__(256) abs_rowsum_kernel(const double* __restric
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) rowsum[row] = s;
 }
-__global__ void __launch_bounds__(256) max_kernel(const double* __restrict__ v, int count, double* __restrict__ out) {
+__global__ void __launch_bounds__(256) abs_rowsum_kernel(const double* __restrict__ M, int64_t ldm, int n, double* __restrict__ rowsum) { abs_rowsum_kernel_body(M, ldm, n, rowsum); }
+NK_BATCHED_TWIN(abs_rowsum_kernel, (256), const double*, int64_t, int, double*)
+__device__ __forceinline__ void max_kernel_body(const double* __restrict__ v, int count, double* __restrict__ out) {
   __shared__ double sh[4];
   double s = 0.0;
   for (int i = threadIdx.x; i < count; i += blockDim.x) s = fmax(s, v[i]);
@@ -139,13 +148,12 @@ __global__ void __launch_bounds__(256) max_kernel(const double* __restrict__ v, 
   __syncthreads();
   if (threadIdx.x == 0) out[0] = fmax(fmax(sh[0], sh[1]), fmax(sh[2], sh[3]));
 }
+__global__ void __launch_bounds__(256) max_kernel(const double* __restrict__ v, int count, double* __restrict__ out) { max_kernel_body(v, count, out); }
+NK_BATCHED_TWIN(max_kernel, (256), const double*, int, double*)
 
 // Column sums of squared differences (the RMSE scorer): each workgroup reduces a slab of rows for 64 columns with
 // coalesced row reads; wavefront reduction across the 4 waves through LDS; per-slab partials are summed in order.
-__global__ void __launch_bounds__(256) colsum_sqdiff_partial_kernel(const double* __restrict__ P, int64_t ldp,
-                                                                    const double* __restrict__ Y, int64_t ldy,
-                                                                    int64_t rows, int cols, int rows_per_block,
-                                                                    double* __restrict__ partial) {
+__device__ __forceinline__ void colsum_sqdiff_partial_kernel_body(const double* __restrict__ P, int64_t ldp, const double* __restrict__ Y, int64_t ldy, int64_t rows, int cols, int rows_per_block, double* __restrict__ partial) {
   __shared__ double sh[4][64];
   const int col = blockIdx.x * 64 + (threadIdx.x & 63);
   const int w = threadIdx.x >> 6;
@@ -162,14 +170,17 @@ __global__ void __launch_bounds__(256) colsum_sqdiff_partial_kernel(const double
   if (w == 0 && col < cols)
     partial[(int64_t)blockIdx.y * cols + col] = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
 }
-__global__ void colsum_finish_kernel(const double* __restrict__ partial, int nslabs, int cols,
-                                     double* __restrict__ colsum) {
+__global__ void __launch_bounds__(256) colsum_sqdiff_partial_kernel(const double* __restrict__ P, int64_t ldp, const double* __restrict__ Y, int64_t ldy, int64_t rows, int cols, int rows_per_block, double* __restrict__ partial) { colsum_sqdiff_partial_kernel_body(P, ldp, Y, ldy, rows, cols, rows_per_block, partial); }
+NK_BATCHED_TWIN(colsum_sqdiff_partial_kernel, (256), const double*, int64_t, const double*, int64_t, int64_t, int, int, double*)
+__device__ __forceinline__ void colsum_finish_kernel_body(const double* __restrict__ partial, int nslabs, int cols, double* __restrict__ colsum) {
   const int col = blockIdx.x * blockDim.x + threadIdx.x;
   if (col >= cols) return;
   double s = 0.0;
   for (int k = 0; k < nslabs; ++k) s += partial[(int64_t)k * cols + col];
   colsum[col] = s;
 }
+__global__ void __launch_bounds__(256) colsum_finish_kernel(const double* __restrict__ partial, int nslabs, int cols, double* __restrict__ colsum) { colsum_finish_kernel_body(partial, nslabs, cols, colsum); }
+NK_BATCHED_TWIN(colsum_finish_kernel, (256), const double*, int, int, double*)
 
 static inline int grid_for(int64_t total, int num_cu) {
   int64_t b = (total + 255) / 256;
@@ -394,6 +405,7 @@ int sqrtm_spd_coupled(nk_ctx* ctx, const double* P, int64_t ldp, int m, double* 
   }
   if (iters) *iters = it;
   if (resid) *resid = r;
+  NK_TRY(x_align());
   if (!ok) {
     set_error("sqrtm: Newton-Schulz did not converge (residual %g after %d iterations)", r, it);
     arena_release(ctx, mk);
@@ -414,10 +426,12 @@ int launch_potrf_diag_pair(nk_ctx* ctx, double* const* Ajj, const int64_t* lda, 
                            int nsys, int blk);
 
 // failure flags and [min, max] pivot slots of the current stream's two systems: flags <- 0, min <- +inf, max <- 0
-__global__ void reset_pivots_kernel(int* info, unsigned long long* piv) {
+__device__ __forceinline__ void reset_pivots_kernel_body(int* info, unsigned long long* piv) {
   if (threadIdx.x < 4) piv[threadIdx.x] = (threadIdx.x & 1) ? 0ull : 0x7FF0000000000000ull;
   if (threadIdx.x < 2) info[threadIdx.x] = 0;
 }
+__global__ void __launch_bounds__(256) reset_pivots_kernel(int* info, unsigned long long* piv) { reset_pivots_kernel_body(info, piv); }
+NK_BATCHED_TWIN(reset_pivots_kernel, (256), int*, unsigned long long*)
 static int reset_pivots(nk_ctx* ctx) {
   hipLaunchKernelGGL(reset_pivots_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->d_info + info_base(ctx),
                      ctx->d_piv + 2 * info_base(ctx));
@@ -658,9 +672,7 @@ int cholesky_solve(nk_ctx* ctx, const double* L, int64_t ldl, int m, const doubl
 // ---------------------------------------------------------------------------------------------------------------
 // Xt = L * s on and below the diagonal, zero above (the factorisation leaves the old upper triangle in place);
 // X = Xt^T;  s = 1 / sqrt(d_c[0])
-__global__ void __launch_bounds__(256) tri_scale_both_kernel(const double* __restrict__ L, int64_t ldl, int m,
-                                                             const double* __restrict__ d_c, double* __restrict__ Xt,
-                                                             double* __restrict__ X) {
+__device__ __forceinline__ void tri_scale_both_kernel_body(const double* __restrict__ L, int64_t ldl, int m, const double* __restrict__ d_c, double* __restrict__ Xt, double* __restrict__ X) {
   __shared__ double tile[32][33];
   const double s = 1.0 / sqrt(d_c[0]);
   const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
@@ -678,6 +690,8 @@ __global__ void __launch_bounds__(256) tri_scale_both_kernel(const double* __res
     if (i < m && j < m) X[(int64_t)i * m + j] = tile[tx][r];
   }
 }
+__global__ void __launch_bounds__(256) tri_scale_both_kernel(const double* __restrict__ L, int64_t ldl, int m, const double* __restrict__ d_c, double* __restrict__ Xt, double* __restrict__ X) { tri_scale_both_kernel_body(L, ldl, m, d_c, Xt, X); }
+NK_BATCHED_TWIN(tri_scale_both_kernel, (256), const double*, int64_t, int, const double*, double*, double*)
 
 int sqrtm_prepare(nk_ctx* ctx, const double* P, int64_t ldp, int m, SqrtPlan* plan) {
   plan->P = P; plan->ldp = ldp; plan->m = m;
@@ -732,8 +746,7 @@ int sqrtm_prepare(nk_ctx* ctx, const double* P, int64_t ldp, int m, SqrtPlan* pl
 // convergence bookkeeping of the queued iteration: fixed-order sum of the per-block partials of sum (M - I)^2, then
 // state[0] = step + 1 of the first step whose residual is below 1e-7 (0: not yet), state[1] = that residual,
 // state[2] = last residual seen
-__global__ void __launch_bounds__(256) ns_flag_kernel(const double* __restrict__ partial, int count, int m, int step,
-                                                      double* __restrict__ state) {
+__device__ __forceinline__ void ns_flag_kernel_body(const double* __restrict__ partial, int count, int m, int step, double* __restrict__ state) {
   __shared__ double sh[4];
   double s = 0.0;
   for (int i = threadIdx.x; i < count; i += blockDim.x) s += partial[i];
@@ -749,6 +762,8 @@ __global__ void __launch_bounds__(256) ns_flag_kernel(const double* __restrict__
     }
   }
 }
+__global__ void __launch_bounds__(256) ns_flag_kernel(const double* __restrict__ partial, int count, int m, int step, double* __restrict__ state) { ns_flag_kernel_body(partial, count, m, step, state); }
+NK_BATCHED_TWIN(ns_flag_kernel, (256), const double*, int, int, int, double*)
 
 // S = Q^T L^T = sqrt(c) Q^T X_0 ;  S^-1 = L^-T Q = (L^-1)^T Q with L^-1 = (extra rows)^T   (Q = the converged iterate)
 // Q_even / select: the iterate after an even number of steps and the device word holding the step count (queued form)
@@ -988,6 +1003,7 @@ int sqrtm_finish(nk_ctx* ctx, SqrtPlan* plan, double* S, double* Sinv) {
   }
   plan->iters = it;
   plan->resid = r;
+  NK_TRY(x_align());  // lock-step groups: the iteration count differs from unit to unit; re-align the launch sequences here
   if (!ok) {
     set_error("sqrtm: Newton-Schulz did not converge (residual %g after %d iterations)", r, it);
     arena_release(ctx, plan->mark);

@@ -56,7 +56,7 @@ __device__ __forceinline__ void store_tile(double* T, int ldt, d4 acc, int l15, 
   for (int reg = 0; reg < 4; ++reg) T[(l4 + 4 * reg) * ldt + l15] = acc[reg];
 }
 
-__global__ void __launch_bounds__(64) potrf_diag_kernel(PotrfBatch pb, int blk) {
+__device__ __forceinline__ void potrf_diag_kernel_body(const PotrfBatch& pb, int blk) {
   constexpr int NB = CHOL_NB;
   static_assert(NB == 64, "one lane per row, four 16-column panels");
   const int which = blockIdx.x;  // one wave per system of a paired factorisation
@@ -214,6 +214,13 @@ __global__ void __launch_bounds__(64) potrf_diag_kernel(PotrfBatch pb, int blk) 
     atomicMax(pb.piv[which] + 1, (unsigned long long)__double_as_longlong(piv_max));
   }
 }
+__global__ void __launch_bounds__(64) potrf_diag_kernel(PotrfBatch pb, int blk) { potrf_diag_kernel_body(pb, blk); }
+__global__ void __launch_bounds__(64) potrf_diag_kernel_batched(const nk::ArgPack<PotrfBatch, int>* table) {
+  potrf_diag_kernel_body(table[blockIdx.z].v, table[blockIdx.z].rest.v);
+}
+static nk::TwinReg potrf_twin_reg(reinterpret_cast<const void*>(static_cast<void (*)(PotrfBatch, int)>(potrf_diag_kernel)),
+                                  reinterpret_cast<const void*>(potrf_diag_kernel_batched),
+                                  sizeof(nk::ArgPack<PotrfBatch, int>), "potrf_diag_kernel");
 
 // Ajj/lda/nb/Linv: per system (nb <= 0 skips a system); failures are flagged in ctx->d_info[info_base + system]
 int launch_potrf_diag_pair(nk_ctx* ctx, double* const* Ajj, const int64_t* lda, const int* nb, double* const* Linv,

@@ -60,12 +60,14 @@ int launch_lifted_step(nk_ctx* ctx, const double* G, int64_t ldg, int m, int mz,
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// The whole recursion in ONE launch when G = [A | B] fits in LDS (m <= 128): one 1024-thread workgroup per trajectory
-// keeps G resident in LDS (row-major, lanes read consecutive k: conflict-free) and walks all T steps with one workgroup
-// barrier per step; trajectories of a batch run side by side on different CUs.  The arithmetic per output row is that
-// of lifted_step_kernel (lane-strided partial sums over z then u, shuffle tree, + bias), so both paths give the same
-// bits.  Optionally the lift of the initial state, z_0 = K_mm^{-1/2} k(Z, x_0) (regressors.py:171-178), is done by the
-// same workgroup first (wave per landmark / per row), so that a rollout is one kernel + one product with C.
+// The whole recursion in ONE launch when G = [A | B] fits in the REGISTERS of one workgroup (m <= 128, m + p <= 136):
+// one 1024-thread workgroup per trajectory, thread (row = tid / 8, part = tid % 8) keeps G[row][part + 8 j], j < 17, in
+// VGPRs for all T steps -- G is loop invariant, so a step touches LDS only for the current vector [z ; u] (8 distinct
+// addresses per wave instruction, broadcast to the 8 rows of the wave: conflict-free), does 17 FMAs, three DPP adds
+// across the 8 parts and one workgroup barrier.  Trajectories of a batch run side by side on different CUs.  Controls
+// and bias are staged in LDS (a global / page-locked read inside the step loop would put 1-3 us on the critical path of
+// every step).  Optionally the lift of the initial state, z_0 = K_mm^{-1/2} k(Z, x_0) (regressors.py:171-178), is done by
+// the same workgroup first (wave per landmark), so that a rollout is one kernel + one product with C.
 // ---------------------------------------------------------------------------------------------------------------
 struct ChainParams {
   const double* G; int64_t ldg; int m, pu;          // z' = G [z; u] + bias
@@ -77,9 +79,13 @@ struct ChainParams {
   const double* bias; int64_t bias_stride;           // [b][m] or shared (stride 0); may be null
   double* Zall; int64_t z_stride;                    // [b][t][m]
   int T;
+  int tb;                                            // steps per staged block of controls
+  int d_pad;                                         // LDS doubles reserved for the scaled x0 (lift)
 };
 
 constexpr int CHAIN_THREADS = 1024;
+constexpr int CHAIN_KPT = 17;               // G entries per thread
+constexpr int CHAIN_ZU = 8 * CHAIN_KPT;     // padded length of [z ; u] in LDS (136)
 
 __device__ __forceinline__ double chain_kfun(int ktype, double acc, double sigma0sq) {
   if (ktype == NK_KERNEL_RBF) return exp(-0.5 * acc);
@@ -93,19 +99,30 @@ __device__ __forceinline__ double chain_kfun(int ktype, double acc, double sigma
 __global__ void __launch_bounds__(CHAIN_THREADS) lifted_chain_kernel(ChainParams P) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int m = P.m, pu = P.pu, mpu = m + pu;
-  const int ldgs = mpu + (mpu & 1);
-  double* Gs = lds;                          // m x ldgs
-  double* zu0 = Gs + (size_t)m * ldgs;       // two buffers of [z ; u]
-  double* zu1 = zu0 + ldgs;
-  double* kv = zu1 + ldgs;                   // m kernel values (lift)
-  double* xw = kv + m + (m & 1);             // d scaled coordinates of x0 (lift)
+  double* zu0 = lds;                         // two buffers of [z ; u], zero padded to CHAIN_ZU
+  double* zu1 = zu0 + CHAIN_ZU;
+  double* kv = zu1 + CHAIN_ZU;               // m kernel values (lift)
+  double* biasS = kv + 128;                  // m
+  double* xw = biasS + 128;                  // d scaled coordinates of x0 (lift)
+  double* Ublk = xw + P.d_pad;               // P.tb x pu
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = CHAIN_THREADS / 64;
+  const int row = tid >> 3, part = tid & 7;
   const int b = blockIdx.x;
-  for (int e = tid; e < m * mpu; e += CHAIN_THREADS) {
-    const int r = e / mpu, c = e - r * mpu;
-    Gs[(size_t)r * ldgs + c] = P.G[(int64_t)r * P.ldg + c];
+  double g[CHAIN_KPT];
+#pragma unroll
+  for (int j = 0; j < CHAIN_KPT; ++j) {
+    const int k = part + 8 * j;
+    g[j] = (row < m && k < mpu) ? P.G[(int64_t)row * P.ldg + k] : 0.0;
   }
+  if (tid < 2 * CHAIN_ZU) zu0[tid] = 0.0;    // both buffers: the padding must read as zero
   double* zall = P.Zall + (int64_t)b * P.z_stride;
+  if (P.bias) {
+    const double* bias = P.bias + (int64_t)b * P.bias_stride;
+    if (tid < m) biasS[tid] = bias[tid];
+  } else if (tid < m) {
+    biasS[tid] = 0.0;
+  }
+  __syncthreads();
   if (P.lift) {
     const double* x0 = P.x0 + (int64_t)b * P.x0_stride;
     const bool linear = P.ktype == NK_KERNEL_LINEAR;
@@ -135,30 +152,43 @@ __global__ void __launch_bounds__(CHAIN_THREADS) lifted_chain_kernel(ChainParams
     }
   } else {
     const double* z0 = P.z0 + (int64_t)b * P.z0_stride;
-    for (int k = tid; k < m; k += CHAIN_THREADS) { const double v = z0[k]; zu0[k] = v; zall[k] = v; }
+    if (tid < m) { const double v = z0[tid]; zu0[tid] = v; zall[tid] = v; }
   }
   const double* U = P.U ? P.U + (int64_t)b * P.u_stride : nullptr;
-  const double* bias = P.bias ? P.bias + (int64_t)b * P.bias_stride : nullptr;
-  if (tid < pu && P.T > 1) zu0[m + tid] = U[tid];
-  __syncthreads();
+  const int kpt = (mpu + 7) >> 3;
+  const bool wave_active = (wave << 3) < m;
   double* cur = zu0;
   double* nxt = zu1;
-  for (int t = 0; t + 1 < P.T; ++t) {
-    for (int r = wave; r < m; r += nwaves) {
-      const double* g = Gs + (size_t)r * ldgs;
-      double acc = 0.0;
-      for (int k = lane; k < m; k += 64) acc = fma(g[k], cur[k], acc);
-      for (int k = lane; k < pu; k += 64) acc = fma(g[m + k], cur[m + k], acc);
-      const double sres = wave_sum64(acc);
-      if (lane == 0) {
-        const double v = sres + (bias ? bias[r] : 0.0);
-        nxt[r] = v;
-        zall[(int64_t)(t + 1) * m + r] = v;
-      }
+  for (int t0 = 0; t0 + 1 < P.T; t0 += P.tb) {
+    const int steps = min(P.tb, P.T - 1 - t0);
+    __syncthreads();  // the previous block's last reads of Ublk are done
+    if (U) {
+      for (int e = tid; e < steps * pu; e += CHAIN_THREADS) Ublk[e] = U[(int64_t)t0 * pu + e];
     }
-    if (tid < pu && t + 2 < P.T) nxt[m + tid] = U[(int64_t)(t + 1) * pu + tid];
     __syncthreads();
-    double* sw = cur; cur = nxt; nxt = sw;
+    if (U && tid < pu) cur[m + tid] = Ublk[tid];
+    __syncthreads();
+    for (int ts = 0; ts < steps; ++ts) {
+      double acc = 0.0;
+      if (wave_active) {  // waves whose 8 rows all lie beyond m idle (uniform branch); kpt = ceil((m + pu) / 8) <= 17
+#pragma unroll
+        for (int j = 0; j < CHAIN_KPT; ++j)
+          if (j < kpt) acc = fma(g[j], cur[part + 8 * j], acc);
+      }
+      acc += __shfl_xor(acc, 1, 64);
+      acc += __shfl_xor(acc, 2, 64);
+      acc += __shfl_xor(acc, 4, 64);
+      if (part == 0 && row < m) {
+        const double v = acc + biasS[row];
+        nxt[row] = v;
+        zall[(int64_t)(t0 + ts + 1) * m + row] = v;
+      }
+      if (U && tid < pu && ts + 1 < steps) nxt[m + tid] = Ublk[(ts + 1) * pu + tid];
+      // LDS-only barrier: __syncthreads() would also wait for the global store above to retire (vmcnt(0), ~1 us per step);
+      // nothing in this workgroup reads zall back, so only the LDS writes need to be visible
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      double* sw = cur; cur = nxt; nxt = sw;
+    }
   }
 }
 
@@ -184,30 +214,40 @@ int launch_ref_minus_traj(nk_ctx* ctx, const double* ref, int64_t ref_stride, co
   return NK_OK;
 }
 
-size_t lifted_chain_lds_bytes(int m, int pu, int d_lift) {
-  const int mpu = m + pu, ldgs = mpu + (mpu & 1);
-  return ((size_t)m * ldgs + 2 * (size_t)ldgs + (size_t)(m + (m & 1)) + (size_t)(d_lift > 0 ? d_lift : 0) + 2) * sizeof(double);
-}
+static inline int chain_d_pad(int d_lift) { return d_lift > 0 ? d_lift + (d_lift & 1) : 0; }
+// LDS doubles without the control block
+static size_t chain_fixed_doubles(int d_lift) { return 2 * (size_t)CHAIN_ZU + 256 + (size_t)chain_d_pad(d_lift) + 2; }
+constexpr size_t CHAIN_LDS_MAX = 64 * 1024;
 bool lifted_chain_ok(int m, int pu, int d_lift) {
-  return m >= 1 && m <= 128 && pu >= 0 && pu <= CHAIN_THREADS && lifted_chain_lds_bytes(m, pu, d_lift) <= 160 * 1024;
+  if (!(m >= 1 && m <= 128 && pu >= 0 && m + pu <= CHAIN_ZU)) return false;
+  return (chain_fixed_doubles(d_lift) + (size_t)pu * 16) * sizeof(double) <= CHAIN_LDS_MAX;  // >= 16 steps of controls per block
 }
 
 static bool g_chain_attr_set = false;
 
 int launch_lifted_chain(nk_ctx* ctx, const ChainArgs& a) {
-  NK_REQUIRE(lifted_chain_ok(a.m, a.pu, a.lift ? a.d : 0), "lifted_chain: operators do not fit in LDS");
+  const int dl = a.lift ? a.d : 0;
+  NK_REQUIRE(lifted_chain_ok(a.m, a.pu, dl), "lifted_chain: operators do not fit in LDS");
   NK_REQUIRE(a.batch >= 1 && a.T >= 1, "lifted_chain: bad sizes");
-  const size_t bytes = lifted_chain_lds_bytes(a.m, a.pu, a.lift ? a.d : 0);
+  const int pu = a.U ? a.pu : 0;
+  const size_t fixed = chain_fixed_doubles(dl) * sizeof(double);
+  int tb = a.T > 1 ? a.T - 1 : 1;
+  if (pu > 0) {
+    const size_t room = (CHAIN_LDS_MAX - fixed) / (sizeof(double) * (size_t)pu);
+    if ((size_t)tb > room) tb = (int)room;
+    if (tb > 1024) tb = 1024;
+  }
+  const size_t bytes = fixed + (size_t)tb * (size_t)pu * sizeof(double);
   if (!g_chain_attr_set) {
     NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lifted_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               160 * 1024));
+                               (int)CHAIN_LDS_MAX));
     g_chain_attr_set = true;
   }
   ChainParams P;
   P.G = a.G; P.ldg = a.ldg; P.m = a.m; P.pu = a.pu; P.z0 = a.z0; P.z0_stride = a.z0_stride; P.lift = a.lift ? 1 : 0;
   P.x0 = a.x0; P.x0_stride = a.x0_stride; P.Zl = a.Zl; P.d = a.d; P.winv = a.winv; P.Sinv = a.Sinv; P.ktype = a.ktype;
   P.sigma0sq = a.sigma0 * a.sigma0; P.U = a.pu > 0 ? a.U : nullptr; P.u_stride = a.u_stride; P.bias = a.bias;
-  P.bias_stride = a.bias_stride; P.Zall = a.Zall; P.z_stride = a.z_stride; P.T = a.T;
+  P.bias_stride = a.bias_stride; P.Zall = a.Zall; P.z_stride = a.z_stride; P.T = a.T; P.tb = tb; P.d_pad = chain_d_pad(dl);
   hipLaunchKernelGGL(lifted_chain_kernel, dim3(a.batch), dim3(CHAIN_THREADS), bytes, ctx->stream, P);
   NK_HIP(hipGetLastError());
   return NK_OK;

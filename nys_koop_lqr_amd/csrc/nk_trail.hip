@@ -26,7 +26,7 @@ struct TrailBatch {
   TrailSys s[2];
 };
 
-__global__ void __launch_bounds__(256) chol_trail_kernel(TrailBatch tb) {
+__device__ __forceinline__ void chol_trail_kernel_body(const TrailBatch& tb) {
   const TrailSys s = tb.s[blockIdx.y];
   if ((int)blockIdx.x >= s.nblocks) return;
   __builtin_amdgcn_s_setprio(2);  // latency-bound chain beside the GEMM-bound side stream
@@ -94,6 +94,10 @@ __global__ void __launch_bounds__(256) chol_trail_kernel(TrailBatch tb) {
         }
       }
 }
+__global__ void __launch_bounds__(256) chol_trail_kernel(TrailBatch tb) { chol_trail_kernel_body(tb); }
+__global__ void __launch_bounds__(256) chol_trail_kernel_batched(const nk::ArgPack<TrailBatch>* table) { chol_trail_kernel_body(table[blockIdx.z].v); }
+static nk::TwinReg chol_trail_kernel_twin_reg(reinterpret_cast<const void*>(static_cast<void (*)(TrailBatch)>(chol_trail_kernel)),
+                                 reinterpret_cast<const void*>(chol_trail_kernel_batched), sizeof(nk::ArgPack<TrailBatch>), "chol_trail_kernel");
 
 // trailing updates of up to two systems; calls[q] as prepared for the generic engine (A = B = panel, K = 64, alpha = -1,
 // beta = 1, TRI_LOWER).  Returns false when a call does not have that shape (the caller then uses the generic engine).
@@ -139,7 +143,7 @@ struct PanelBatch {
   PanelSys s[2];
 };
 
-__global__ void __launch_bounds__(256) chol_panel_kernel(PanelBatch pb) {
+__device__ __forceinline__ void chol_panel_kernel_body(const PanelBatch& pb) {
   const PanelSys s = pb.s[blockIdx.y];
   if ((int)blockIdx.x >= s.nblocks) return;
   __builtin_amdgcn_s_setprio(2);
@@ -189,6 +193,10 @@ __global__ void __launch_bounds__(256) chol_panel_kernel(PanelBatch pb) {
         if (row < s.rows) s.P[(int64_t)row * s.ldp + 16 * j + l15] = acc[i][j][reg];
       }
 }
+__global__ void __launch_bounds__(256) chol_panel_kernel(PanelBatch pb) { chol_panel_kernel_body(pb); }
+__global__ void __launch_bounds__(256) chol_panel_kernel_batched(const nk::ArgPack<PanelBatch>* table) { chol_panel_kernel_body(table[blockIdx.z].v); }
+static nk::TwinReg chol_panel_kernel_twin_reg(reinterpret_cast<const void*>(static_cast<void (*)(PanelBatch)>(chol_panel_kernel)),
+                                 reinterpret_cast<const void*>(chol_panel_kernel_batched), sizeof(nk::ArgPack<PanelBatch>), "chol_panel_kernel");
 
 // panel products of up to two systems; calls[q] as prepared for the generic engine (C = A in place, B = Linv_jj with
 // leading dimension 64, N = K = 64, alpha = 1, beta = 0).  false: not that shape.

@@ -37,7 +37,7 @@ constexpr int TR_ROWS = 16 * TR_RT;  // rows per workgroup; wave w owns columns 
 constexpr int TR_PA = TR_ROWS / 4;    // doubles per thread of a cooperative band-block load (256 threads, 64 columns)
 constexpr int TLD = 65;      // odd row stride: the 16 rows an operand fetch touches fall into distinct LDS banks
 
-__global__ void __launch_bounds__(256) trsm_right_lower_kernel(TrsmBatch tb) {
+__device__ __forceinline__ void trsm_right_lower_kernel_body(const TrsmBatch& tb) {
   constexpr int NB = CHOL_NB;
   const int q = (tb.nsys > 1 && (int)blockIdx.x >= tb.s[1].wg_begin) ? 1 : 0;
   const TrsmSys s = tb.s[q];
@@ -171,6 +171,13 @@ __global__ void __launch_bounds__(256) trsm_right_lower_kernel(TrsmBatch tb) {
     __syncthreads();
   }
 }
+__global__ void __launch_bounds__(256) trsm_right_lower_kernel(TrsmBatch tb) { trsm_right_lower_kernel_body(tb); }
+__global__ void __launch_bounds__(256) trsm_right_lower_kernel_batched(const nk::ArgPack<TrsmBatch>* table) {
+  trsm_right_lower_kernel_body(table[blockIdx.z].v);
+}
+static nk::TwinReg trsm_twin_reg(reinterpret_cast<const void*>(static_cast<void (*)(TrsmBatch)>(trsm_right_lower_kernel)),
+                                 reinterpret_cast<const void*>(trsm_right_lower_kernel_batched), sizeof(nk::ArgPack<TrsmBatch>),
+                                 "trsm_right_lower_kernel");
 
 // E_q <- E_q L_q^-1 for up to two systems (E: extra x m rows below the factor in the same array, see CholSys)
 int launch_trsm_right_lower_pair(nk_ctx* ctx, const CholSys* sys, int nsys) {

@@ -71,7 +71,7 @@ def cv_unit_score(X, Y, n_inputs, params, fold, centers_idx=None, error_score=np
     rows = np.where(centers_idx < lo, centers_idx, centers_idx + (hi - lo))  # training-row index -> dataset row
     reg.nystrom_centers_output = np.asarray(Y)[rows].T
     try:
-        reg.fit(X, Y, row_ranges=[(0, lo), (hi, n)])
+        reg.fit(X, Y, row_ranges=[(0, lo), (hi, n)], fetch=False)  # the sweep only scores: A, B, C stay on the device
         return reg.score_neg_rmse(X[lo:hi], Y[lo:hi])
     except (np.linalg.LinAlgError, _lib.NyskoopError) as e:
         if isinstance(error_score, str) and error_score == "raise":
@@ -90,7 +90,8 @@ def _rank_candidates(scores):
     return mean, best
 
 
-def grid_search_cv(X, Y, n_inputs, candidates, n_splits=5, centers=None, work=None, workers=1, error_score=np.nan):
+def grid_search_cv(X, Y, n_inputs, candidates, n_splits=5, centers=None, work=None, workers=1, error_score=np.nan,
+                   batch=0, batch_groups=1):
     """learn_hyperparams (benchmark_lqr_cloth.py:39-66 and the classic/hjb twins) without sklearn's process pool.
 
     candidates: list of dicts with keys kernel / gamma / m.  centers: optional {(c, f): landmark indices into the
@@ -99,7 +100,9 @@ def grid_search_cv(X, Y, n_inputs, candidates, n_splits=5, centers=None, work=No
     not evaluated are NaN.  workers: host threads issuing units concurrently on this GPU (each thread has its own
     context and streams; small fits are latency bound, so several in flight fill the chip).  The landmark draws happen
     up front in GridSearchCV's order, so the scores do not depend on `workers`.  error_score: score of a unit whose fit
-    fails numerically (GridSearchCV's default: nan; such a candidate ranks last), or 'raise'.
+    fails numerically (GridSearchCV's default: nan; such a candidate ranks last), or 'raise'.  batch: run that many
+    units in lock step (include/nyskoop.h, nk_group_create): small fits are chains of launch-bound kernels, a batch shares
+    every launch; scores are bit-identical to batch=0.
     Returns split_scores (n_cand x n_splits), mean_test_score, best_index.
     """
     X = np.ascontiguousarray(X, dtype=np.float64)
@@ -122,7 +125,39 @@ def grid_search_cv(X, Y, n_inputs, candidates, n_splits=5, centers=None, work=No
         c, f, idx = item
         return c, f, cv_unit_score(X, Y, n_inputs, candidates[c], folds[f], idx, error_score)
 
-    if workers > 1 and len(todo) > 1:
+    if batch > 1 and len(todo) > 1:
+        # lock-step batching (nk_cv_grid): `batch` units per round, one library thread each, kernel launches merged
+        units = []
+        for (c, f, idx) in todo:
+            lo, hi = folds[f]
+            idx = np.asarray(idx)
+            rows = np.where(idx < lo, idx, idx + (hi - lo))  # training-row index -> dataset row
+            kern = candidates[c]["kernel"].kernel
+            units.append((kern, candidates[c]["gamma"], 1e-6, candidates[c]["m"], (lo, hi), rows))
+        if batch_groups > 1 and len(units) >= 2 * batch:
+            # several independent lock-step groups, each on its own stream and driven from its own host thread: the
+            # latency-bound factorisation chains of one group overlap with the GEMM-bound stages of another
+            from concurrent.futures import ThreadPoolExecutor
+            shares = [list(range(gi, len(units), batch_groups)) for gi in range(batch_groups)]
+            sc, status = np.full(len(units), np.nan), np.zeros(len(units), dtype=np.int32)
+
+            def run_share(gi):
+                sub = [units[i] for i in shares[gi]]
+                return _lib.lockstep_pool(batch, index=gi).cv_grid(X, Y, n_inputs, sub)
+
+            with ThreadPoolExecutor(max_workers=batch_groups) as ex:
+                for gi, (s_g, st_g) in enumerate(ex.map(run_share, range(batch_groups))):
+                    sc[shares[gi]], status[shares[gi]] = s_g, st_g
+        else:
+            sc, status = _lib.lockstep_pool(batch).cv_grid(X, Y, n_inputs, units)
+        bad = [int(st) for st in status if st not in (0, -3, -5)]
+        if bad:
+            raise _lib.NyskoopError(bad[0], "a unit of the batched sweep failed")
+        if isinstance(error_score, str) and error_score == "raise" and np.any(status != 0):
+            raise np.linalg.LinAlgError("a unit of the batched sweep failed numerically")
+        sc = np.where(status == 0, sc, float("nan") if isinstance(error_score, str) else float(error_score))
+        results = [(c, f, float(s)) for (c, f, _), s in zip(todo, sc)]
+    elif workers > 1 and len(todo) > 1:
         results = list(_lib.worker_pool(workers).map(run, todo))
     else:
         results = [run(item) for item in todo]

@@ -145,11 +145,19 @@ class KoopmanNystromRegressor(KoopmanRegressor):
     def _wait_fetch(self):
         if self.__dict__.get("_fetching"):
             self.__dict__["_fetching"] = False
-            _lib.check(_lib.load_library().nk_model_wait(self._model))
+            if self.__dict__.get("_fetch_lazy"):  # fit(..., fetch=False): copy the operators now, on first use
+                self.__dict__["_fetch_lazy"] = False
+                ctx = _lib.get_context()
+                G, Cm, Wm = self.__dict__["_A"].base, self.__dict__["_C"], self.__dict__["_weights"]
+                _lib.check(ctx.lib.nk_model_get_ops(ctx.handle, self._model, G.ctypes.data, G.shape[1], Cm.ctypes.data,
+                                                    Cm.shape[1], Wm.ctypes.data, Wm.shape[1]))
+            else:
+                _lib.check(_lib.load_library().nk_model_wait(self._model))
 
     def __getstate__(self):
         self._wait_fetch()
         state = dict(self.__dict__)
+        state["_fetch_lazy"] = False
         state["_model"] = None  # device handles never travel (benchmark_lqr_cloth.py:266-267 pickles regressors)
         state["_model_key"] = None
         return state
@@ -252,25 +260,31 @@ class KoopmanNystromRegressor(KoopmanRegressor):
             raise np.linalg.LinAlgError(ctx.lib.nk_last_error().decode())
         _lib.check(rc)
 
-    def _adopt(self, ctx, h, stats, m, d, p, t_host):
-        """Take over a freshly fitted device model: queue the copies of the operators into page-locked arrays."""
+    def _adopt(self, ctx, h, stats, m, d, p, t_host, fetch=True):
+        """Take over a freshly fitted device model: queue the copies of the operators into page-locked arrays
+        (fetch=False: leave them on the device until an attribute is read -- sweeps that only score never pay the copy)."""
         t_host2 = time.perf_counter()
         self._model = h
         self._stats = stats.as_dict()
-        G = _lib.pinned_empty((m, m + p))  # page-locked: the device->host copies run at the PCIe rate
-        Cm = _lib.pinned_empty((d, m))
-        Wm = _lib.pinned_empty((d, m + p))
+        if fetch:
+            G = _lib.pinned_empty((m, m + p))  # page-locked: the device->host copies run at the PCIe rate
+            Cm = _lib.pinned_empty((d, m))
+            Wm = _lib.pinned_empty((d, m + p))
+        else:
+            G, Cm, Wm = np.empty((m, m + p)), np.empty((d, m)), np.empty((d, m + p))
         t_host2b = time.perf_counter()
         self.__dict__.update(_A=G[:, :m], _B=G[:, m:], _C=Cm, _weights=Wm)  # A, B: views of G_ls (regressors.py:158-159)
-        _lib.check(ctx.lib.nk_model_get_ops_async(ctx.handle, h, G.ctypes.data, m + p, Cm.ctypes.data, m,
-                                                  Wm.ctypes.data, m + p))
+        if fetch:
+            _lib.check(ctx.lib.nk_model_get_ops_async(ctx.handle, h, G.ctypes.data, m + p, Cm.ctypes.data, m,
+                                                      Wm.ctypes.data, m + p))
+        self.__dict__["_fetch_lazy"] = not fetch
         self._fetching = True
         t_host3 = time.perf_counter()
         self._stats.update(host_ms_drop=(t_host[1] - t_host[0]) * 1e3, host_ms_call=(t_host2 - t_host[1]) * 1e3,
                            host_ms_fetch=(t_host3 - t_host2) * 1e3, host_ms_pinned=(t_host2b - t_host2) * 1e3)
         self._model_key = self._ops_key()
 
-    def fit(self, X, Y, row_ranges=None):
+    def fit(self, X, Y, row_ranges=None, fetch=True):
         """regressors.py:122-169.  X: n x (d+p) rows [state | input], Y: n x d (NumPy arrays, or float64 device
         tensors already resident in HBM).  Returns None, like the reference."""
         ctx = _lib.get_context()
@@ -292,7 +306,7 @@ class KoopmanNystromRegressor(KoopmanRegressor):
                                     None if same else Zi.ctypes.data, d, Zo.ctypes.data, d, m,
                                     float(self.gamma), float(self.jitter), C.byref(h), C.byref(stats))
         self._raise(ctx, rc)
-        self._adopt(ctx, h, stats, m, d, p, (t_host0, t_host1))
+        self._adopt(ctx, h, stats, m, d, p, (t_host0, t_host1), fetch)
 
     # ------------------------------------------------------------------------- sample-sharded fit
     def gram_size(self, d):

@@ -64,8 +64,12 @@ def test_cloth_cv_grid_full_shape_vs_reference_gridsearch(nk, golden):
         cands.append(dict(kernel=nk.ThreeDimensionalKernel(*ls, 192), gamma=float(g["order_gamma"][c]), m=int(g["m"])))
     np.random.seed(int(g["seed"]))
     t0 = time.perf_counter()
-    res = harness.grid_search_cv(X, Y, 6, cands, n_splits=5, workers=4)
+    res = harness.grid_search_cv(X, Y, 6, cands, n_splits=5, batch=32, batch_groups=2)  # lock-step batched (nk_cv_grid)
     dt = time.perf_counter() - t0
+    # the batched sweep computes the very bits of the one-unit-at-a-time path: replay the first three candidates unbatched
+    np.random.seed(int(g["seed"]))
+    ref3 = harness.grid_search_cv(X, Y, 6, cands[:3], n_splits=5)
+    assert np.array_equal(ref3["split_scores"], res["split_scores"][:3])
     sc, ref = res["split_scores"], g["split_scores"]
     assert sc.shape == ref.shape == (81, 5) and np.all(np.isfinite(sc))
     rel = np.abs(sc - ref) / np.abs(ref)
