@@ -58,10 +58,11 @@ def all_gather_scores(local_scores, n_units, rank, world):
 
 
 def sharded_grid_search(X, Y, n_inputs, candidates, n_splits=5, centers=None, unit_fn=None, seed=None, workers=1,
-                        error_score=np.nan):
+                        error_score=np.nan, batch=0, batch_groups=1):
     """Distributed counterpart of harness.grid_search_cv.  Landmarks: `centers[(c, f)]` if given, otherwise drawn
     from a per-unit RandomState(seed + unit index) so that the result does not depend on the world size.
     A unit whose fit fails numerically scores `error_score` (nan by default, like GridSearchCV) and the sweep goes on.
+    batch / batch_groups: run each rank's share through the lock-step batched sweep (harness.grid_search_cv).
     Every rank returns the same dict (split_scores, mean_test_score, best_index, best_params)."""
     import torch.distributed as dist
     rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_initialized() else (0, 1)
@@ -83,7 +84,21 @@ def sharded_grid_search(X, Y, n_inputs, candidates, n_splits=5, centers=None, un
             return unit_fn(X, Y, n_inputs, candidates[c], folds[f], idx, error_score)
         return unit_fn(X, Y, n_inputs, candidates[c], folds[f], idx)
 
-    if workers > 1 and len(mine) > 1:  # several latency-bound fits in flight per GPU (one context per thread)
+    if batch > 1 and unit_fn is harness.cv_unit_score and len(mine) > 1:
+        # this rank's share through the lock-step batched sweep (nk_cv_grid): same scores, several thousand units/s
+        def landmarks(u):
+            c, f = units[u]
+            if centers is not None:
+                return centers[(c, f)]
+            n_train = X.shape[0] - (folds[f][1] - folds[f][0])
+            rs = np.random.RandomState((0 if seed is None else int(seed)) + u)
+            return rs.choice(np.arange(0, n_train), size=candidates[c]["m"], replace=False)
+        my_units = [units[u] for u in mine]
+        res = harness.grid_search_cv(X, Y, n_inputs, candidates, n_splits=n_splits,
+                                     centers={units[u]: landmarks(u) for u in mine}, work=my_units, batch=batch,
+                                     batch_groups=batch_groups, error_score=error_score)
+        local = [res["split_scores"][c, f] for (c, f) in my_units]
+    elif workers > 1 and len(mine) > 1:  # several latency-bound fits in flight per GPU (one context per thread)
         from ._lib import worker_pool
         local = list(worker_pool(workers).map(run, mine))
     else:

@@ -114,7 +114,7 @@ def grid_search_cv(X, Y, n_inputs, candidates, n_splits=5, centers=None, work=No
     todo = []
     for (c, f) in units:
         if centers is not None:
-            idx = centers[(c, f)]
+            idx = centers.get((c, f)) if (c, f) not in mine else centers[(c, f)]
         else:  # drawn for every unit, evaluated or not: keeps the RNG stream aligned with the serial sweep
             n_train = X.shape[0] - (folds[f][1] - folds[f][0])
             idx = np.random.choice(np.arange(0, n_train), size=candidates[c]["m"], replace=False)

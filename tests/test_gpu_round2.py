@@ -396,3 +396,72 @@ print("OK", float(a[0, 0]) == float(a[0, 0]))
         out = subprocess.run([sys.executable, "-c", code] + extra, capture_output=True, text=True, timeout=300)
         assert out.returncode == 0, (out.returncode, out.stdout[-500:], out.stderr[-2000:])
         assert "OK" in out.stdout
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# lock-step batching of small fits (nk_group_*, nk_cv_grid)
+# ---------------------------------------------------------------------------------------------------------------
+def _cv_problem(nk, n=505, d=24, p=2, m=64, ncand=6, seed=4):
+    rng = np.random.default_rng(seed)
+    S = rng.standard_normal((n, d))
+    U = rng.standard_normal((n, p))
+    Y = np.tanh(S @ (rng.standard_normal((d, d)) * 0.8 / np.sqrt(d))) + U @ (rng.standard_normal((p, d)) * 0.1)
+    X = np.hstack([S, U])
+    ls = (2.0, 4.0, 8.0)
+    cands = [dict(kernel=nk.ThreeDimensionalKernel(l, l, l, d), gamma=g, m=m) for l in ls for g in (1e-5, 1e-3)][:ncand]
+    folds = [(0, 101), (101, 202), (202, 303), (303, 404), (404, 505)]
+    centers = {(c, f): np.random.RandomState(31 * c + f).choice(n - 101, m, replace=False) for c in range(len(cands))
+               for f in range(5)}
+    return X, Y, p, cands, centers
+
+
+@pytest.mark.parametrize("batch,groups", [(4, 1), (16, 1), (7, 2), (40, 1)])
+def test_lockstep_batched_sweep_is_bit_identical(nk, batch, groups):
+    """The batched sweep (members of a lock-step group, launches merged into blockIdx.z-batched twins) computes exactly
+    the bits of the one-unit-at-a-time sweep: same kernels, same arguments.  d = 24 takes the direct-difference kernel
+    blocks; folds 1-3 have two row ranges (gathered), folds 0 and 4 one; the candidates need different numbers of
+    square-root iterations (alignment points)."""
+    from nys_koop_lqr_amd import harness, _lib
+    X, Y, p, cands, centers = _cv_problem(nk)
+    base = harness.grid_search_cv(X, Y, p, cands, centers=centers)
+    res = harness.grid_search_cv(X, Y, p, cands, centers=centers, batch=batch, batch_groups=groups)
+    assert np.array_equal(res["split_scores"], base["split_scores"])
+    assert res["best_index"] == base["best_index"]
+    st = _lib.lockstep_pool(batch).stats()
+    assert st["merged_launches"] > 0 and st["member_launches_merged"] > st["merged_launches"]
+
+
+def test_lockstep_gram_form_blocks_and_failing_unit(nk):
+    """d >= 32: Gram-form kernel blocks on the MFMA engine inside a batch; one candidate (duplicated landmarks, tiny gamma)
+    takes the SVD fallback inside its unit while the others go on -- its kernels have no twin and run one member at a time."""
+    from nys_koop_lqr_amd import harness
+    X, Y, p, cands, centers = _cv_problem(nk, d=48, m=96, ncand=4, seed=9)
+    cands[1] = dict(kernel=cands[1]["kernel"], gamma=1e-13, m=96)
+    for f in range(5):
+        base_idx = centers[(1, f)][:88]
+        centers[(1, f)] = np.concatenate([base_idx, base_idx[:8]])
+    one = harness.grid_search_cv(X, Y, p, cands, centers=centers)
+    res = harness.grid_search_cv(X, Y, p, cands, centers=centers, batch=10)
+    assert np.all(np.isfinite(one["split_scores"]))
+    assert np.array_equal(res["split_scores"], one["split_scores"])
+
+
+def test_lockstep_pool_runs_ordinary_api_calls(nk, O):
+    """Members of a group driven through the ordinary estimator API from their own threads (fit, lift, predict, rollout,
+    operator fetch): every call works inside and outside a unit of work and equals the ungrouped result."""
+    from nys_koop_lqr_amd import _lib
+    reg0, ref, X, Y, rng = _fitted(nk, O, n=400, d=10, p=2, m=40, seed=21)
+    d = Y.shape[1]
+    Useq = rng.standard_normal((2, 12))
+    want = (np.array(reg0.A), reg0.predict(X[:20]), reg0.rollout(X[0, :d], Useq))
+
+    def unit(k):
+        reg = nk.KoopmanNystromRegressor(2, kernel=reg0.kernel, gamma=reg0.gamma, m=40)
+        reg.nystrom_centers_output = reg0.nystrom_centers_output
+        reg.fit(X, Y)
+        return np.array(reg.A), reg.predict(X[:20]), reg.rollout(X[0, :d], Useq)
+
+    pool = _lib.lockstep_pool(5, index=7)
+    for got in pool.map(unit, range(8)):  # a full round of 5 and a partial round of 3
+        for a, b in zip(got, want):
+            assert np.array_equal(a, b)
