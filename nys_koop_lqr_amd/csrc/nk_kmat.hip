@@ -136,6 +136,82 @@ __global__ void __launch_bounds__(256, 2) kmat_kernel_batched(const nk::ArgPack<
 NK_KMAT_TWIN(0) NK_KMAT_TWIN(1) NK_KMAT_TWIN(2)
 
 
+// ---------------------------------------------------------------------------------------------------------------
+// Small state dimension (d <= 8: the Duffing / HJB configs of benchmark_lqr_classic.py and _hjb.py, d = 2 and 1).  The
+// build is bound by the HBM WRITE of the output (8 B per entry against <= 2 d flop of distance work): the tiled kernel
+// above spends its time in LDS staging and 8 x 8 register tiles that have nothing to amortise.  Here the output (row-major, rows of
+// nB entries at stride ldo) is walked as one flat index space: a thread produces two consecutive entries per step and stores them as one 16-byte
+// word, a wave writes 1 KiB contiguous, the grid strides over the array.  The landmark rows (pre-scaled by 1/lengthscale)
+// sit in LDS, the sample row is read through the cache (64 lanes share at most two rows).  Same arithmetic per entry as
+// the tiled kernel (differences of pre-scaled coordinates, sequential FMA over the dimensions), hence the same bits.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int KFLAT_DMAX = 8;
+template <int KTYPE>
+__device__ __forceinline__ void kmat_flat_body(const double* __restrict__ A, int64_t lda, int64_t nA, const double* __restrict__ B,
+                                               int64_t ldb, int nB, int d, const double* __restrict__ winv, double sigma0sq,
+                                               double* __restrict__ out, int64_t ldo, int64_t step_i, int step_j) {
+  extern __shared__ __attribute__((aligned(16))) double kf_lds[];
+  double* Bs = kf_lds;          // nB x d, pre-scaled
+  double* ws = Bs + (size_t)nB * d;
+  for (int e = threadIdx.x; e < nB * d; e += 256) {
+    const int j = e / d, k = e - j * d;
+    Bs[e] = B[(int64_t)j * ldb + k] * winv[k];
+  }
+  if (threadIdx.x < d) ws[threadIdx.x] = winv[threadIdx.x];
+  __syncthreads();
+  const int64_t total = nA * (int64_t)nB;
+  int64_t e = 2 * ((int64_t)blockIdx.x * 256 + threadIdx.x);
+  int64_t i = e / nB;
+  int j = (int)(e - i * nB);
+  for (; e < total; e += 2 * (int64_t)gridDim.x * 256) {
+    const double* arow = A + i * lda;
+    double acc0 = 0.0, acc1 = 0.0;
+    const double* b0 = Bs + (size_t)j * d;
+#pragma unroll
+    for (int k = 0; k < KFLAT_DMAX; ++k) {
+      if (k < d) {
+        const double a = arow[k] * ws[k];
+        if (KTYPE == NK_KERNEL_LINEAR) {
+          acc0 = fma(a, b0[k], acc0);
+          acc1 = fma(a, b0[d + k], acc1);
+        } else {
+          const double d0 = a - b0[k], d1 = a - b0[d + k];
+          acc0 = fma(d0, d0, acc0);
+          acc1 = fma(d1, d1, acc1);
+        }
+      }
+    }
+    *reinterpret_cast<double2*>(out + i * ldo + j) = make_double2(kmat_epilogue<KTYPE>(acc0, sigma0sq), kmat_epilogue<KTYPE>(acc1, sigma0sq));
+    i += step_i;
+    j += step_j;
+    if (j >= nB) { j -= nB; ++i; }
+  }
+}
+template <int KTYPE>
+__global__ void __launch_bounds__(256) kmat_flat_kernel(const double* __restrict__ A, int64_t lda, int64_t nA,
+                                                        const double* __restrict__ B, int64_t ldb, int nB, int d,
+                                                        const double* __restrict__ winv, double sigma0sq,
+                                                        double* __restrict__ out, int64_t ldo, int64_t step_i,
+                                                        int step_j) {
+  kmat_flat_body<KTYPE>(A, lda, nA, B, ldb, nB, d, winv, sigma0sq, out, ldo, step_i, step_j);
+}
+template <int KTYPE>
+__global__ void __launch_bounds__(256) kmat_flat_kernel_batched(
+    const nk::ArgPack<const double*, int64_t, int64_t, const double*, int64_t, int, int, const double*, double, double*, int64_t, int64_t, int>* table) {
+  const nk::ArgPack<const double*, int64_t, int64_t, const double*, int64_t, int, int, const double*, double, double*, int64_t, int64_t, int> p =
+      table[blockIdx.z];
+  nk::pack_apply([](auto... a) { kmat_flat_body<KTYPE>(a...); }, p);
+}
+#define NK_KFLAT_TWIN(K)                                                                                                  \
+  static nk::TwinReg kflat_twin_reg_##K(                                                                                  \
+      reinterpret_cast<const void*>(static_cast<void (*)(const double*, int64_t, int64_t, const double*, int64_t, int, int, \
+                                                         const double*, double, double*, int64_t, int64_t, int)>(kmat_flat_kernel<K>)), \
+      reinterpret_cast<const void*>(kmat_flat_kernel_batched<K>),                                                           \
+      sizeof(nk::ArgPack<const double*, int64_t, int64_t, const double*, int64_t, int, int, const double*, double, double*, \
+                         int64_t, int64_t, int>),                                                                                  \
+      "kmat_flat_kernel<" #K ">");
+NK_KFLAT_TWIN(0) NK_KFLAT_TWIN(1) NK_KFLAT_TWIN(2)
+
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 int launch_kmat(nk_ctx* ctx, int ktype, const double* A, int64_t lda, int64_t nA, const double* B, int64_t ldb,
@@ -147,6 +223,30 @@ int launch_kmat(nk_ctx* ctx, int ktype, const double* A, int64_t lda, int64_t nA
   const int vecA = aligned16(A) && lda % 2 == 0, vecB = aligned16(B) && ldb % 2 == 0;
   const int vecO = aligned16(out) && ldo % 2 == 0;
   const double s2 = sigma0 * sigma0;
+  if (d <= KFLAT_DMAX && ldo % 2 == 0 && nB % 2 == 0 && aligned16(out) && (size_t)(nB * d + d) * 8 <= 60 * 1024 &&
+      nA * nB >= 4096 && ktype >= NK_KERNEL_RBF && ktype <= NK_KERNEL_LINEAR) {
+    // write-bound regime: flat streaming kernel
+    const int64_t pairs = nA * nB / 2;
+    int64_t blocks = (pairs + 255) / 256;
+    const int64_t cap = (int64_t)ctx->num_cu * 8;
+    if (blocks > cap) blocks = cap;
+    const int64_t stride = 2 * blocks * 256;  // elements advanced per grid-stride step
+    const int64_t step_i = stride / nB;
+    const int step_j = (int)(stride - step_i * nB);
+    const size_t lds = (size_t)(nB * d + d) * 8;
+    const dim3 g((unsigned)blocks);
+    if (ktype == NK_KERNEL_RBF)
+      hipLaunchKernelGGL((kmat_flat_kernel<NK_KERNEL_RBF>), g, dim3(256), lds, ctx->stream, A, lda, nA, B, ldb, (int)nB, d,
+                         winv, s2, out, ldo, step_i, step_j);
+    else if (ktype == NK_KERNEL_MATERN52)
+      hipLaunchKernelGGL((kmat_flat_kernel<NK_KERNEL_MATERN52>), g, dim3(256), lds, ctx->stream, A, lda, nA, B, ldb, (int)nB,
+                         d, winv, s2, out, ldo, step_i, step_j);
+    else
+      hipLaunchKernelGGL((kmat_flat_kernel<NK_KERNEL_LINEAR>), g, dim3(256), lds, ctx->stream, A, lda, nA, B, ldb, (int)nB, d,
+                         winv, s2, out, ldo, step_i, step_j);
+    NK_HIP(hipGetLastError());
+    return NK_OK;
+  }
   switch (ktype) {
     case NK_KERNEL_RBF:
       hipLaunchKernelGGL((kmat_kernel<NK_KERNEL_RBF>), grid, dim3(256), 0, ctx->stream, A, lda, (int)nA, B, ldb,

@@ -20,6 +20,10 @@ which = sys.argv[1] if len(sys.argv) > 1 else "duffing"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 if which == "duffing":
     n, m, d, kern = 69900, 200, 2, nk.KernelWrapper([1.0, 1.0]).kernel
+elif which == "duffing_rbf":
+    n, m, d, kern = 69900, 200, 2, nk.ThreeDimensionalKernel(1.0, 1.0, 1.0, 2).kernel
+elif which == "duffing_linear":
+    n, m, d, kern = 69900, 200, 2, nk.LinearKernelWrapper(0.5).kernel
 else:
     n, m, d, kern = 30300, 500, 192, nk.ThreeDimensionalKernel(10.0, 10.0, 10.0, 192).kernel
 rng = np.random.default_rng(0)
