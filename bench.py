@@ -89,25 +89,27 @@ def cpu_baseline_full(X, Y, idx, ls, gamma, p, threads, timed=2, budget_s=240.0)
         tw = wreg.timings
         predicted = tw["fixed"] + (tw["kernel_n"] + tw["gram_n"]) * (n / rows)
         if predicted > budget_s:
-            return None
+            return None, None
         timed = max(1, min(timed, int(budget_s // predicted)))
         walls, stages = [], None
         for _ in range(timed):
             w, reg = _oracle_fit(O, X, Y, Z, ls, gamma, p)
             walls.append(w)
             stages = reg.timings
-        fast = None
-        if predicted * (timed + 0.3) < budget_s:
-            fast, _ = _oracle_fit(O, X, Y, Z, ls, gamma, p, faithful=False)
+        # the de-pessimised CPU form (eigh square root once + Cholesky solves), from the 10 % sample, n-proportional stages
+        # scaled: reported so that the speed-up is not inflated by the reference's avoidable O(m^3) work
+        _, freg = _oracle_fit(O, X[:rows], Y[:rows], Z, ls, gamma, p, faithful=False)
+        tf = freg.timings
+        fast = tf["fixed"] + (tf["kernel_n"] + tf["gram_n"]) * (n / rows)
     med = float(np.median(walls))
     return dict(value=1.0 / med, unit="fits/s", cores=threads, kind="port", protocol="full-size",
                 seconds_per_fit=walls, spread_rel=float((max(walls) - min(walls)) / med),
-                os_cpu_count=os.cpu_count(), blas_threads=blas, fast_mode_value=None if fast is None else 1.0 / fast,
+                os_cpu_count=os.cpu_count(), blas_threads=blas, fast_mode_value_extrapolated=1.0 / fast,
                 sample=(f"oracle in reference-faithful mode (cdist+exp, sqrtm x2, solve(her), lstsq x2) on the full workload "
                         f"n={n} m={len(idx)} d={d}: warm-up on a 10% row sample ({warm:.1f} s), then {timed} timed full-size "
                         f"fit(s) {['%.1f' % w for w in walls]} s (last: {stages['kernel_n']:.1f} s kernel builds + "
                         f"{stages['gram_n']:.1f} s Gram + {stages['fixed']:.1f} s O(m^3)); cdist/exp are single-threaded; "
-                        f"fast_mode_value = the same algebra with eigh square root + Cholesky"))
+                        f"fast_mode_value_extrapolated = the same algebra with eigh square root + Cholesky, from the 10% sample")), reg
 
 
 def cpu_baseline_sample(X, Y, idx, ls, gamma, p, sample_rows, threads):
@@ -323,13 +325,22 @@ def main():
             out["cv_sweep"] = cv_sweep_rate(nk)
         mode = "none" if args.no_cpu_baseline else args.cpu_baseline
         if world == 1 and mode != "none":
-            base = None
+            base, oracle_fit = None, None
             if mode == "full":
-                base = cpu_baseline_full(X, Y, idx, 20.0, 1e-6, p, args.cpu_threads)
+                base, oracle_fit = cpu_baseline_full(X, Y, idx, 20.0, 1e-6, p, args.cpu_threads)
             if base is None:
                 base = cpu_baseline_sample(X, Y, idx, 20.0, 1e-6, p, min(args.cpu_sample_rows, n), args.cpu_threads)
             out["cpu_baseline"] = base
             out["gpu_over_cpu"] = value / base["value"]
+            if oracle_fit is not None and not sweep:
+                # the timed CPU leg IS the reference-faithful oracle on the full workload with the same landmarks and
+                # hyper-parameters: relative Frobenius distance of the GPU operators of the last timed fit from it
+                rel = lambda a, b: float(np.linalg.norm(np.asarray(a) - b) / np.linalg.norm(b))
+                fc = oracle_fit.predict(X[:256])
+                out["parity_full_size"] = dict(A=rel(last.A, oracle_fit.A), B=rel(last.B, oracle_fit.B),
+                                               C=rel(last.C, oracle_fit.C), W=rel(last.weights, oracle_fit.weights),
+                                               predict=rel(last.predict(X[:256]), fc),
+                                               against="oracle, reference-faithful mode, full n (the cpu_baseline fit)")
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

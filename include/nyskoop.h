@@ -94,8 +94,8 @@ int nk_set_kmat_mode(nk_ctx* ctx, int mode);
 /* Rank-deficient regularised systems.  scipy.linalg.lstsq (regressors.py:155,165; LAPACK gelsd, rcond = eps) silently
  * returns the minimum-norm solution with singular values <= eps * sigma_max dropped.  By default (strict = 0) the library
  * does the same -- a one-sided Jacobi SVD on the device with the same cut-off -- whenever its Cholesky factorisation meets
- * a non-positive pivot or pivots that span more than 1/(order * eps) (1/(8 * order * eps) in nk_solve_spd), i.e. a matrix
- * that is singular to working precision.  (A system whose Cholesky succeeds with healthy pivots is solved at full rank even if its singular values
+ * a non-positive pivot or an isolated cluster of rounding-level pivots (<= 8 order eps d_max, separated from the other pivots
+ * by a factor 1000: an exact null space), i.e. a matrix that is singular to working precision.  (A system whose Cholesky succeeds with healthy pivots is solved at full rank even if its singular values
  * reach below eps * sigma_max: there gelsd's rank decision is taken inside its own rounding noise and no two solvers
  * agree on it -- DESIGN.md section 3.)  strict = 1 turns the fallback into NK_ERR_NOT_SPD (also: environment variable
  * NYSKOOP_STRICT_SPD=1 before nk_create). */

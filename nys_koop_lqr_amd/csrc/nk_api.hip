@@ -1055,8 +1055,11 @@ static int fit_impl(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int6
   NK_TRY(arena_alloc_t(ctx, (size_t)m * ldd, &Wc));
   NK_TRY(arena_alloc_t(ctx, (size_t)m * ldd, &Ct));
   CholSys sys[2];
+  double* pivlog = nullptr;
+  NK_TRY(arena_alloc_t(ctx, (size_t)mp + m + 4, &pivlog));
   sys[0].P = G1; sys[0].ldp = mp; sys[0].m = mp; sys[0].Linv = Linv; sys[0].extra = m;   // [inner; cross]
   sys[1].P = G3; sys[1].ldp = m; sys[1].m = m; sys[1].Linv = Linv2; sys[1].extra = d;    // [inner_rec; left_rec]
+  sys[0].pivlog = pivlog; sys[1].pivlog = pivlog + mp + (mp & 1);
   // both systems advance in lock step (paired launches); the per-block kernels are latency bound and leave the chip
   // mostly idle ...
   NK_TRY(cholesky_aug_pair_async(ctx, sys, 2));  // G2 <- cross inner^-1 (m x mp) ; G4 <- left_rec inner_rec^-1 (d x m)
@@ -1115,7 +1118,7 @@ static int fit_impl(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int6
   NK_HIP(hipEventRecord(ev[5], ctx->stream));
   tr.mark("solve issued");
   int chol_failed[2] = {0, 0};
-  NK_TRY(cholesky_fail_flags(ctx, sys, 2, chol_failed, 1.0));  // synchronises the main stream (which has joined the side stream)
+  NK_TRY(cholesky_fail_flags(ctx, sys, 2, chol_failed));  // synchronises the main stream (which has joined the side stream)
   tr.mark("final sync");
   int rank_sys[2] = {mp, m};
   bool redo_products = false;
@@ -1759,7 +1762,11 @@ int nk_solve_spd(nk_ctx* ctx, const double* P, int64_t ldp, int32_t m, const dou
   NK_TRY(arena_alloc_t(ctx, (size_t)m * ldw, &W));
   NK_TRY(launch_copy2d(ctx, p.ptr, p.ld, L, m, m, m));
   NK_TRY(launch_copy2d(ctx, r.ptr, r.ld, W, ldw, m, nrhs));
-  int rc_chol = cholesky_lower(ctx, L, m, m, Linv);
+  double* pivlog = nullptr;
+  NK_TRY(arena_alloc_t(ctx, (size_t)m, &pivlog));
+  CholSys csys;
+  csys.P = L; csys.ldp = m; csys.m = m; csys.Linv = Linv; csys.pivlog = pivlog;
+  int rc_chol = cholesky_lower_pair(ctx, &csys, 1);
   if (getenv("NYSKOOP_FORCE_PINV")) rc_chol = NK_ERR_NOT_SPD;  // testing hook: always take the SVD path
   if (rc_chol == NK_ERR_NOT_SPD && !ctx->strict_spd) {
     // numerically singular: X = P^+ R with gelsd's cut-off, i.e. X^T = R^T P^+ (P symmetric)

@@ -236,6 +236,7 @@ struct CholSys {
   int extra = 0;
   bool backward = true;  // false: stop after the factorisation (the extra rows then hold R^T L^-T)
   double* Linv = nullptr;
+  double* pivlog = nullptr;  // optional device array of m doubles: the factorisation logs every pivot here
   double* R = nullptr;   // right-hand sides (solve only), overwritten by the solution
   int64_t ldr = 0;
   int nrhs = 0;
@@ -264,7 +265,7 @@ struct PinvInfo {
 int pinv_right_divide(nk_ctx* ctx, const double* P, int64_t ldp, int m, const double* E, int64_t lde, int rows,
                       double* E_out, int64_t ldeo, double rcond, PinvInfo* info);
 // which systems of the last (paired) factorisation on the current stream met a non-positive pivot (synchronises)
-int cholesky_fail_flags(nk_ctx* ctx, const CholSys* sys, int nsys, int* failed /* nsys entries */, double tau_factor);
+int cholesky_fail_flags(nk_ctx* ctx, const CholSys* sys, int nsys, int* failed /* nsys entries */);
 
 // matrix-vector step of the lifted recursion for up to 8 trajectories (nk_rollout.hip)
 int launch_lifted_step(nk_ctx* ctx, const double* G, int64_t ldg, int m, int mz, int pu, const double* z, int64_t zstride,

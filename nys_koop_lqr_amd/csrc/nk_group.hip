@@ -218,6 +218,10 @@ static void flush_locked(nk_group* g, const std::vector<nk_ctx*>& ready) {
     }
     uint64_t best = 0, best_any = 0;
     int best_n = -1, best_any_n = -1;
+    if (holders.size() == 1) {  // the common case: everybody is at the same launch
+      best = holders.begin()->first;
+      best_n = holders.begin()->second;
+    } else
     for (auto& kv : holders) {
       bool ahead_elsewhere = false;
       for (size_t b = 0; b < R && !ahead_elsewhere; ++b) {

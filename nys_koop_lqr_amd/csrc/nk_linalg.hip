@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <vector>
 
 namespace nk {
 
@@ -423,7 +424,7 @@ int sqrtm_spd_coupled(nk_ctx* ctx, const double* P, int64_t ldp, int m, double* 
 // ---------------------------------------------------------------------------------------------------------------
 // potrf_diag_kernel lives in nk_potrf.hip (fully unrolled, slow to compile)
 int launch_potrf_diag_pair(nk_ctx* ctx, double* const* Ajj, const int64_t* lda, const int* nb, double* const* Linv,
-                           int nsys, int blk);
+                           int nsys, int blk, double* const* plog);
 
 // failure flags and [min, max] pivot slots of the current stream's two systems: flags <- 0, min <- +inf, max <- 0
 __device__ __forceinline__ void reset_pivots_kernel_body(int* info, unsigned long long* piv) {
@@ -449,6 +450,7 @@ int cholesky_lower_pair_async(nk_ctx* ctx, const CholSys* sys, int nsys) {
     const int j0 = jb * NB;
     double* Ajj[2] = {nullptr, nullptr};
     double* Li[2] = {nullptr, nullptr};
+    double* Pl[2] = {nullptr, nullptr};
     int64_t lda[2] = {0, 0};
     int nbj[2] = {0, 0};
     GemmCall panel[2], trail[2];
@@ -459,6 +461,7 @@ int cholesky_lower_pair_async(nk_ctx* ctx, const CholSys* sys, int nsys) {
       Ajj[q] = y.P + (int64_t)j0 * y.ldp + j0;
       lda[q] = y.ldp;
       Li[q] = y.Linv + (size_t)jb * NB * NB;
+      Pl[q] = y.pivlog ? y.pivlog + j0 : nullptr;
       const int rem = y.m - j0 - nbj[q];
       if (rem > 0) {
         double* pnl = y.P + (int64_t)(j0 + nbj[q]) * y.ldp + j0;
@@ -473,7 +476,7 @@ int cholesky_lower_pair_async(nk_ctx* ctx, const CholSys* sys, int nsys) {
         trail[q].opts.tri = TRI_LOWER;
       }
     }
-    NK_TRY(launch_potrf_diag_pair(ctx, Ajj, lda, nbj, Li, nsys, jb));
+    NK_TRY(launch_potrf_diag_pair(ctx, Ajj, lda, nbj, Li, nsys, jb, Pl));
     {
       int rc_panel = NK_OK;  // 64 x 64 panel product: specialised kernel (nk_trail.hip), generic engine otherwise
       if (!launch_chol_panel_pair(ctx, panel, nsys, &rc_panel)) NK_TRY(launch_gemm_pair(ctx, false, true, panel, nsys));
@@ -491,44 +494,55 @@ int cholesky_lower_pair_async(nk_ctx* ctx, const CholSys* sys, int nsys) {
 // Host-side verdict of the factorisations queued by cholesky_lower_pair_async (synchronises the current stream).
 int cholesky_check_pair(nk_ctx* ctx, const CholSys* sys, int nsys) {
   int failed[2] = {0, 0};
-  NK_TRY(cholesky_fail_flags(ctx, sys, nsys, failed, 8.0));
+  NK_TRY(cholesky_fail_flags(ctx, sys, nsys, failed));
   for (int q = 0; q < nsys; ++q)
     if (failed[q] != 0) {
       if (failed[q] > 0)
         set_error("Cholesky: non-positive pivot at index %d of %d (system %d is numerically rank deficient; the "
                   "reference's lstsq would truncate here)", failed[q] - 1, sys[q].m, q);
       else
-        set_error("Cholesky: pivots of system %d (order %d) span more than 1/(8 m eps): singular to working precision (the "
-                  "reference's lstsq would truncate here)", q, sys[q].m);
+        set_error("Cholesky: system %d (order %d) has an isolated cluster of rounding-level pivots: an exact null space (the "
+                  "reference's lstsq truncates it)", q, sys[q].m);
       return NK_ERR_NOT_SPD;
     }
   return NK_OK;
 }
 
 // Verdict of the (paired) factorisation queued last on the current stream: failed[q] > 0 when system q met a
-// non-positive pivot (index + 1), -1 when its pivots say it is singular to working precision:
-// d_min <= tau_factor m eps d_max.  m eps |P| is the backward-error level of the factorisation, below which a pivot is
-// indistinguishable from zero (an exact null space -- duplicated landmarks, say -- shows up like this when rounding
-// happens to leave the pivot positive).  tau_factor: 1 inside a fit, whose right-hand sides have no component along such
-// a null space (the same duplicated landmarks annihilate them), so a rounding-level pivot is harmless and many merely
-// ill-conditioned hyper-parameter candidates have genuine pivots of 1e-13 d_max; 8 (a margin for d_max < |P|) for the
-// general-purpose nk_solve_spd, where an accepted rounding-level pivot multiplies an arbitrary right-hand side by 1e15.  The caller then
-// takes the SVD path, which applies gelsd's own rule (sigma <= eps sigma_max) to decide the rank, so a system that merely
-// looks suspicious here but is full rank by that rule is still solved at full rank.  Synchronises the current stream.
-int cholesky_fail_flags(nk_ctx* ctx, const CholSys* sys, int nsys, int* failed, double tau_factor) {
+// non-positive pivot (index + 1), -1 when its pivots show an EXACT null space: a cluster of pivots at the rounding level of
+// the factorisation (<= 8 m eps d_max) that a factor >= 1000 separates from all other pivots -- duplicated landmarks,
+// a rank-deficient Gram matrix -- where rounding merely happened to leave the pivots positive.  (Needs sys[q].pivlog; without it
+// only d_min <= eps d_max counts.)  A spectrum that decays CONTINUOUSLY to that level -- the ill-conditioned kernel systems of
+// a hyper-parameter grid: genuine pivots of 1e-13 d_max across the whole gamma = 1e-7 row of the cloth grid -- has no such
+// gap and is solved at full rank: there the reference's own rank decision is rounding noise and the
+// SVD path would cost 100 x more for an answer no closer to it.  Synchronises the current stream.
+int cholesky_fail_flags(nk_ctx* ctx, const CholSys* sys, int nsys, int* failed) {
   const int ib = info_base(ctx);
+  std::vector<double> plog[2];
   NK_HIP(hipMemcpyAsync(ctx->h_info + ib, ctx->d_info + ib, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   NK_HIP(hipMemcpyAsync(ctx->h_piv + 2 * ib, ctx->d_piv + 2 * ib, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost,
                         ctx->stream));
+  for (int q = 0; q < nsys; ++q)
+    if (sys[q].pivlog) {
+      plog[q].resize((size_t)sys[q].m);
+      NK_HIP(hipMemcpyAsync(plog[q].data(), sys[q].pivlog, sizeof(double) * sys[q].m, hipMemcpyDeviceToHost, ctx->stream));
+    }
   NK_HIP(hipStreamSynchronize(ctx->stream));
+  const double eps = 2.220446049250313e-16;
   for (int q = 0; q < nsys; ++q) {
     failed[q] = ctx->h_info[ib + q];
-    if (failed[q] == 0) {
-      double dmin, dmax;
-      memcpy(&dmin, &ctx->h_piv[2 * (ib + q)], 8);
-      memcpy(&dmax, &ctx->h_piv[2 * (ib + q) + 1], 8);
-      if (dmax > 0.0 && dmin <= tau_factor * (double)sys[q].m * 2.220446049250313e-16 * dmax) failed[q] = -1;
-    }
+    if (failed[q] != 0) continue;
+    double dmin, dmax;
+    memcpy(&dmin, &ctx->h_piv[2 * (ib + q)], 8);
+    memcpy(&dmax, &ctx->h_piv[2 * (ib + q) + 1], 8);
+    if (!(dmax > 0.0)) continue;
+    if (dmin <= eps * dmax) { failed[q] = -1; continue; }
+    if (plog[q].empty()) continue;
+    std::sort(plog[q].begin(), plog[q].end());
+    const double window = 8.0 * (double)sys[q].m * eps * dmax;
+    size_t k = 0;
+    while (k < plog[q].size() && plog[q][k] <= window) ++k;
+    if (k > 0 && k < plog[q].size() && plog[q][k] >= 1000.0 * plog[q][k - 1]) failed[q] = -1;
   }
   return NK_OK;
 }
@@ -552,6 +566,7 @@ int cholesky_aug_pair_async(nk_ctx* ctx, const CholSys* sys, int nsys, hipEvent_
     const int j0 = jb * NB;
     double* Ajj[2] = {nullptr, nullptr};
     double* Li[2] = {nullptr, nullptr};
+    double* Pl[2] = {nullptr, nullptr};
     int64_t lda[2] = {0, 0};
     int nbj[2] = {0, 0};
     GemmCall panel[2], trail[2];
@@ -562,6 +577,7 @@ int cholesky_aug_pair_async(nk_ctx* ctx, const CholSys* sys, int nsys, hipEvent_
       Ajj[q] = y.P + (int64_t)j0 * y.ldp + j0;
       lda[q] = y.ldp;
       Li[q] = y.Linv + (size_t)jb * NB * NB;
+      Pl[q] = y.pivlog ? y.pivlog + j0 : nullptr;
       const int rem = y.m - j0 - nbj[q];      // rows of the square part below the diagonal block
       const int rows = rem + y.extra;         // ... plus the right-hand-side rows
       if (rows > 0) {
@@ -577,7 +593,7 @@ int cholesky_aug_pair_async(nk_ctx* ctx, const CholSys* sys, int nsys, hipEvent_
         }
       }
     }
-    NK_TRY(launch_potrf_diag_pair(ctx, Ajj, lda, nbj, Li, nsys, jb));
+    NK_TRY(launch_potrf_diag_pair(ctx, Ajj, lda, nbj, Li, nsys, jb, Pl));
     {
       int rc_panel = NK_OK;  // 64 x 64 panel product: specialised kernel (nk_trail.hip), generic engine otherwise
       if (!launch_chol_panel_pair(ctx, panel, nsys, &rc_panel)) NK_TRY(launch_gemm_pair(ctx, false, true, panel, nsys));

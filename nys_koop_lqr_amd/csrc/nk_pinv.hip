@@ -47,10 +47,7 @@ __device__ __forceinline__ void rr_pair(int N, int r, int k, int* a, int* b) {
   }
 }
 
-__global__ void __launch_bounds__(256) jacobi_round_kernel(double* __restrict__ W, double* __restrict__ V, int m, int N,
-                                                           int round, double tol,
-                                                           const double* __restrict__ d_small2,
-                                                           int* __restrict__ rot_count) {
+__device__ __forceinline__ void jacobi_round_kernel_body(double* __restrict__ W, double* __restrict__ V, int m, int N, int round, double tol, const double* __restrict__ d_small2, int* __restrict__ rot_count) {
   __shared__ double sh[3][4];
   __shared__ double cs_sn[2];
   int p, q;
@@ -101,9 +98,11 @@ __global__ void __launch_bounds__(256) jacobi_round_kernel(double* __restrict__ 
     vq[k] = sn * vx + cs * vy;
   }
 }
+__global__ void __launch_bounds__(256) jacobi_round_kernel(double* __restrict__ W, double* __restrict__ V, int m, int N, int round, double tol, const double* __restrict__ d_small2, int* __restrict__ rot_count) { jacobi_round_kernel_body(W, V, m, N, round, tol, d_small2, rot_count); }
+NK_BATCHED_TWIN(jacobi_round_kernel, (256), double*, double*, int, int, int, double, const double*, int*)
 
 // sig2[j] = |row j of W|^2, one wave per row
-__global__ void __launch_bounds__(256) row_sumsq_kernel(const double* __restrict__ W, int m, double* __restrict__ sig2) {
+__device__ __forceinline__ void row_sumsq_kernel_body(const double* __restrict__ W, int m, double* __restrict__ sig2) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= m) return;
   double s = 0.0;
@@ -114,11 +113,12 @@ __global__ void __launch_bounds__(256) row_sumsq_kernel(const double* __restrict
   s = wave_sum_p(s);
   if ((threadIdx.x & 63) == 0) sig2[row] = s;
 }
+__global__ void __launch_bounds__(256) row_sumsq_kernel(const double* __restrict__ W, int m, double* __restrict__ sig2) { row_sumsq_kernel_body(W, m, sig2); }
+NK_BATCHED_TWIN(row_sumsq_kernel, (256), const double*, int, double*)
 
 // d_small2[0] = (rcond * max_j |row j of W|)^2: the running estimate of the cut-off (max column norm <= sigma_max, and it
 // converges to sigma_max as the columns become orthogonal).  One workgroup.
-__global__ void __launch_bounds__(256) dead_threshold_kernel(const double* __restrict__ sig2, int m, double rcond,
-                                                             double* __restrict__ d_small2) {
+__device__ __forceinline__ void dead_threshold_kernel_body(const double* __restrict__ sig2, int m, double rcond, double* __restrict__ d_small2) {
   __shared__ double shmax[4];
   double mx = 0.0;
   for (int j = threadIdx.x; j < m; j += 256) mx = fmax(mx, sig2[j]);
@@ -128,6 +128,8 @@ __global__ void __launch_bounds__(256) dead_threshold_kernel(const double* __res
   __syncthreads();
   if (threadIdx.x == 0) d_small2[0] = rcond * rcond * fmax(fmax(shmax[0], shmax[1]), fmax(shmax[2], shmax[3]));
 }
+__global__ void __launch_bounds__(256) dead_threshold_kernel(const double* __restrict__ sig2, int m, double rcond, double* __restrict__ d_small2) { dead_threshold_kernel_body(sig2, m, rcond, d_small2); }
+NK_BATCHED_TWIN(dead_threshold_kernel, (256), const double*, int, double, double*)
 
 // scale[j] = 1 / sigma_j^2 for the singular values that are kept, else 0; out[0] = rank, out[1] = sigma_max,
 // out[2] = smallest retained sigma, out[3] = smallest sigma.  One workgroup.
@@ -137,9 +139,7 @@ __global__ void __launch_bounds__(256) dead_threshold_kernel(const double* __res
 // null space (its members would otherwise land on either side of the cut-off by chance -- and a kept one multiplies the
 // right-hand side by 1e15) and is dropped as a whole.  A spectrum that decays continuously through the window, as those
 // of the ill-conditioned kernel systems do, has no such gap and gets gelsd's rule unchanged.
-__global__ void __launch_bounds__(256) pinv_scale_kernel(const double* __restrict__ sig2, int m, double rcond,
-                                                         double window, double* __restrict__ scale,
-                                                         double* __restrict__ out) {
+__device__ __forceinline__ void pinv_scale_kernel_body(const double* __restrict__ sig2, int m, double rcond, double window, double* __restrict__ scale, double* __restrict__ out) {
   __shared__ double sh[4];
   __shared__ int shcnt[4];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -198,16 +198,20 @@ __global__ void __launch_bounds__(256) pinv_scale_kernel(const double* __restric
     out[3] = mn;
   }
 }
+__global__ void __launch_bounds__(256) pinv_scale_kernel(const double* __restrict__ sig2, int m, double rcond, double window, double* __restrict__ scale, double* __restrict__ out) { pinv_scale_kernel_body(sig2, m, rcond, window, scale, out); }
+NK_BATCHED_TWIN(pinv_scale_kernel, (256), const double*, int, double, double, double*, double*)
 
-__global__ void scale_cols_kernel(double* __restrict__ T, int64_t ldt, int rows, int cols, const double* __restrict__ scale) {
+__device__ __forceinline__ void scale_cols_kernel_body(double* __restrict__ T, int64_t ldt, int rows, int cols, const double* __restrict__ scale) {
   const int64_t total = (int64_t)rows * cols;
   for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
     const int64_t r = e / cols, c = e - r * cols;
     T[r * ldt + c] *= scale[c];
   }
 }
+__global__ void __launch_bounds__(256) scale_cols_kernel(double* __restrict__ T, int64_t ldt, int rows, int cols, const double* __restrict__ scale) { scale_cols_kernel_body(T, ldt, rows, cols, scale); }
+NK_BATCHED_TWIN(scale_cols_kernel, (256), double*, int64_t, int, int, const double*)
 
-__global__ void sumsq_all_kernel(const double* __restrict__ P, int64_t ldp, int m, double* __restrict__ out) {
+__device__ __forceinline__ void sumsq_all_kernel_body(const double* __restrict__ P, int64_t ldp, int m, double* __restrict__ out) {
   __shared__ double sh[4];
   double s = 0.0;
   const int64_t total = (int64_t)m * m;
@@ -221,6 +225,8 @@ __global__ void sumsq_all_kernel(const double* __restrict__ P, int64_t ldp, int 
   __syncthreads();
   if (threadIdx.x == 0) out[0] = sh[0] + sh[1] + sh[2] + sh[3];
 }
+__global__ void __launch_bounds__(256) sumsq_all_kernel(const double* __restrict__ P, int64_t ldp, int m, double* __restrict__ out) { sumsq_all_kernel_body(P, ldp, m, out); }
+NK_BATCHED_TWIN(sumsq_all_kernel, (256), const double*, int64_t, int, double*)
 
 // E_out (rows x m) = E (rows x m) * pinv(P) with gelsd's singular-value cut-off `rcond` (relative to the largest one).
 // P: symmetric m x m (device).  Synchronises the current stream (one host round trip per sweep).

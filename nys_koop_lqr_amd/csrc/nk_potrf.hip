@@ -31,7 +31,9 @@ struct PotrfBatch {
   double* Linv[2];
   int* info[2];
   unsigned long long* piv[2];  // [min, max] pivot of the whole factorisation as bit patterns (positive doubles order like
-                               // their bit patterns): the numerical-rank verdict d_min <= eps * d_max
+                               // their bit patterns)
+  double* plog[2];             // optional: every pivot of this block, in order (the numerical-rank verdict of
+                               // cholesky_fail_flags looks for an isolated cluster of rounding-level pivots)
 };
 
 constexpr int PLD = CHOL_NB + 1;  // LDS row stride of the 64 x 64 images
@@ -68,6 +70,7 @@ __device__ __forceinline__ void potrf_diag_kernel_body(const PotrfBatch& pb, int
   const int64_t lda = pb.lda[which];
   double* __restrict__ Linv = pb.Linv[which];
   int* __restrict__ info = pb.info[which];
+  double* __restrict__ plog = pb.plog[which];
   double piv_min = 1.0e308, piv_max = 0.0;
   __shared__ double As[NB * PLD];
   __shared__ double Iv[NB * PLD];
@@ -95,6 +98,7 @@ __device__ __forceinline__ void potrf_diag_kernel_body(const PotrfBatch& pb, int
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
       double dkk = readlane_f64(R[k], c0 + k);
+      if (lane == 0 && plog != nullptr && c0 + k < nb) plog[c0 + k] = dkk;
       if (!(dkk > 0.0) || !isfinite(dkk)) {
         if (lane == 0 && c0 + k < nb) atomicCAS(info, 0, blk * NB + c0 + k + 1);
         dkk = 1.0;
@@ -224,7 +228,7 @@ static nk::TwinReg potrf_twin_reg(reinterpret_cast<const void*>(static_cast<void
 
 // Ajj/lda/nb/Linv: per system (nb <= 0 skips a system); failures are flagged in ctx->d_info[info_base + system]
 int launch_potrf_diag_pair(nk_ctx* ctx, double* const* Ajj, const int64_t* lda, const int* nb, double* const* Linv,
-                           int nsys, int blk) {
+                           int nsys, int blk, double* const* plog) {
   PotrfBatch pb;
   for (int q = 0; q < 2; ++q) {
     const bool on = q < nsys;
@@ -234,6 +238,7 @@ int launch_potrf_diag_pair(nk_ctx* ctx, double* const* Ajj, const int64_t* lda, 
     pb.Linv[q] = on ? Linv[q] : nullptr;
     pb.info[q] = ctx->d_info + info_base(ctx) + q;
     pb.piv[q] = ctx->d_piv + 2 * (info_base(ctx) + q);
+    pb.plog[q] = (on && plog) ? plog[q] : nullptr;
   }
   hipLaunchKernelGGL(potrf_diag_kernel, dim3(2), dim3(64), 0, ctx->stream, pb, blk);
   NK_HIP(hipGetLastError());
