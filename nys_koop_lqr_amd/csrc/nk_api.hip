@@ -49,6 +49,7 @@ static int arena_new_chunk(nk_ctx* ctx, Arena& a, size_t bytes) {
     return NK_ERR_OOM;
   }
   a.chunks.push_back(c);
+  if (getenv("NYSKOOP_TRACE")) fprintf(stderr, "[nyskoop] arena: new chunk of %zu MiB (%zu chunks)\n", bytes >> 20, a.chunks.size());
   return NK_OK;
 }
 
@@ -1498,10 +1499,55 @@ static inline size_t pad256(size_t doubles) { return ((doubles * 8) + 255) & ~(s
 // z_{t+1} = G [z_t; u_t] (+ bias) for t < T-1 on Zall ([b][t][m], row 0 of every trajectory already holds z_0 unless
 // `chain.lift`), then x = C z for every (b, t).  One launch for the recursion when G fits in LDS, a matrix-vector /
 // GEMM launch per step otherwise.
-static int rollout_steps(nk_ctx* ctx, ChainArgs chain, bool z0_in_place) {
+static bool chain_mw_enabled() {
+  static const bool on = [] { const char* e = getenv("NYSKOOP_CHAIN_MW"); return !(e && e[0] == '0'); }();
+  return on;
+}
+// One multi-workgroup recursion on the device at a time (two side by side can starve each other of workgroup slots,
+// nk_rollout.hip): held from the launch to the synchronisation that ends the call.
+static std::mutex g_chain_mw_mutex;
+
+// Is the single-launch multi-workgroup recursion the path for this chain?  Not inside a lock-step group (its launches
+// are deferred to the group's flush, the mutex could not cover them), not for more trajectories than fit beside each
+// other unless they are few (<= 16: chunks of launches still beat a launch per step; beyond that the per-step GEMM
+// amortises its launches over the batch).
+static bool chain_mw_wanted(nk_ctx* ctx, const ChainArgs& chain) {
+  if (!chain_mw_enabled() || ctx_recording(ctx) || chain.T < 3) return false;
+  if (lifted_chain_ok(chain.m, chain.pu, chain.lift ? chain.d : 0)) return false;
+  if (!lifted_chain_mw_ok(ctx, chain.m, chain.U ? chain.pu : 0)) return false;
+  return chain.batch <= 16 || (int64_t)chain.batch * chain_mw_workgroups(chain.m) <= ctx->num_cu;
+}
+
+static bool chain_mw_gave_up(nk_ctx* ctx) {
+  int row = 0, step = 0, traj = 0;
+  if (!lifted_chain_mw_timed_out(ctx, &row, &step, &traj)) {
+    const char* hook = getenv("NYSKOOP_CHAIN_MW_TEST_GIVEUP");  // test hook: pretend the wait gave up (tests/)
+    return hook != nullptr && hook[0] == '1';
+  }
+  if (getenv("NYSKOOP_TRACE"))
+    fprintf(stderr, "[nyskoop] single-launch recursion timed out (row %d, step %d, trajectory %d): repeating stepwise\n", row,
+            step, traj);
+  return true;
+}
+
+static int rollout_steps(nk_ctx* ctx, ChainArgs chain, bool z0_in_place, bool use_mw) {
   const int m = chain.m, p = chain.pu, T = chain.T, batch = chain.batch;
   if (lifted_chain_ok(m, p, chain.lift ? chain.d : 0)) return launch_lifted_chain(ctx, chain);
   NK_REQUIRE(!chain.lift && z0_in_place, "rollout_steps: internal: the stepwise path needs z_0 in place");
+  if (use_mw) {
+    int nb = ctx->num_cu / chain_mw_workgroups(m);  // trajectories that are resident side by side
+    if (nb < 1) nb = 1;
+    NK_TRY(lifted_chain_mw_reset(ctx));
+    for (int b0 = 0; b0 < batch; b0 += nb) {
+      ChainArgs sub = chain;
+      sub.batch = batch - b0 < nb ? batch - b0 : nb;
+      sub.Zall = chain.Zall + (int64_t)b0 * chain.z_stride;
+      if (chain.U) sub.U = chain.U + (int64_t)b0 * chain.u_stride;
+      if (chain.bias) sub.bias = chain.bias + (int64_t)b0 * chain.bias_stride;
+      NK_TRY(launch_lifted_chain_mw(ctx, sub));
+    }
+    return lifted_chain_mw_fetch_status(ctx);
+  }
   double* Zall = chain.Zall;
   const int64_t ldz = chain.z_stride;
   for (int t = 0; t + 1 < T; ++t) {
@@ -1589,14 +1635,31 @@ static int rollout_impl(nk_ctx* ctx, const nk_model* mdl, const double* G, int64
     NK_TRY(launch_copy2d(ctx, xin.ptr, xin.ld, Zall, ldz, batch, m));
     z0_in_place = true;
   }
-  NK_TRY(rollout_steps(ctx, ch, z0_in_place));
-  NK_TRY(launch_gemm(ctx, false, true, (int64_t)batch * T, d, m, 1.0, Zall, m, Cop, ldc, 0.0, xdev, ldxo));
-  if (out_z) NK_TRY(launch_copy2d(ctx, Zall, m, zdev, ldzo, (int64_t)batch * T, m));
-  if (!small) {
-    NK_TRY(finish_out(ctx, ox));
-    if (out_z) NK_TRY(finish_out(ctx, oz));
+  if (z0_in_place && small && have_u) {
+    // the stepwise / multi-workgroup paths read the controls from every wave of every step: not from page-locked host
+    // memory (an uncached PCIe read per wave, ~30 us per step at m = 500) but from a device copy
+    double* Udev = nullptr;
+    NK_TRY(arena_alloc_t(ctx, (size_t)batch * T * p, &Udev));
+    NK_TRY(launch_copy2d(ctx, uin.ptr, uin.ld, Udev, (int64_t)T * p, batch, (int64_t)T * p));
+    ch.U = Udev;
   }
-  NK_HIP(hipStreamSynchronize(ctx->stream));
+  const bool try_mw = chain_mw_wanted(ctx, ch);
+  std::unique_lock<std::mutex> mw_lock(g_chain_mw_mutex, std::defer_lock);
+  if (try_mw) mw_lock.lock();
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    const bool mw = try_mw && attempt == 0;
+    NK_TRY(rollout_steps(ctx, ch, z0_in_place, mw));
+    NK_TRY(launch_gemm(ctx, false, true, (int64_t)batch * T, d, m, 1.0, Zall, m, Cop, ldc, 0.0, xdev, ldxo));
+    if (out_z) NK_TRY(launch_copy2d(ctx, Zall, m, zdev, ldzo, (int64_t)batch * T, m));
+    if (!small) {
+      NK_TRY(finish_out(ctx, ox));
+      if (out_z) NK_TRY(finish_out(ctx, oz));
+    }
+    NK_HIP(hipStreamSynchronize(ctx->stream));
+    // a wave of the single-launch recursion gave up waiting for its neighbours (the device was oversubscribed): the
+    // trajectories are not valid; z_0 is untouched, so the recursion is repeated with one launch per step
+    if (!(mw && chain_mw_gave_up(ctx))) break;
+  }
   if (small) small_finish(st);
   return NK_OK;
 }
@@ -1687,16 +1750,23 @@ int nk_closed_loop_batch(nk_ctx* ctx, const nk_model* mdl, const double* K, cons
     NK_TRY(launch_copy2d(ctx, f0.ptr, f0.ld, Phi, ch.z_stride, batch, m));
     z0_in_place = true;
   }
-  NK_TRY(rollout_steps(ctx, ch, z0_in_place));
-  // u_t = K (phi_ref - phi_t) for all t: D = 1 phi_ref^T - Phi, U = D K^T
-  NK_TRY(launch_ref_minus_traj(ctx, fr.ptr, fr.ld, Phi, ch.z_stride, Dm, ch.z_stride, steps, m, batch));
-  NK_TRY(launch_gemm(ctx, false, true, (int64_t)batch * steps, p, m, 1.0, Dm, m, k.ptr, k.ld, 0.0, udev, lduo));
-  NK_TRY(launch_gemm(ctx, false, true, (int64_t)batch * steps, d, m, 1.0, Phi, m, mdl->C, m, 0.0, xdev, ldxo));  // x_t = C phi_t
-  if (!small) {
-    NK_TRY(finish_out(ctx, ox));
-    NK_TRY(finish_out(ctx, ou));
+  const bool try_mw = chain_mw_wanted(ctx, ch);
+  std::unique_lock<std::mutex> mw_lock(g_chain_mw_mutex, std::defer_lock);
+  if (try_mw) mw_lock.lock();
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    const bool mw = try_mw && attempt == 0;
+    NK_TRY(rollout_steps(ctx, ch, z0_in_place, mw));
+    // u_t = K (phi_ref - phi_t) for all t: D = 1 phi_ref^T - Phi, U = D K^T
+    NK_TRY(launch_ref_minus_traj(ctx, fr.ptr, fr.ld, Phi, ch.z_stride, Dm, ch.z_stride, steps, m, batch));
+    NK_TRY(launch_gemm(ctx, false, true, (int64_t)batch * steps, p, m, 1.0, Dm, m, k.ptr, k.ld, 0.0, udev, lduo));
+    NK_TRY(launch_gemm(ctx, false, true, (int64_t)batch * steps, d, m, 1.0, Phi, m, mdl->C, m, 0.0, xdev, ldxo));  // x_t = C phi_t
+    if (!small) {
+      NK_TRY(finish_out(ctx, ox));
+      NK_TRY(finish_out(ctx, ou));
+    }
+    NK_HIP(hipStreamSynchronize(ctx->stream));
+    if (!(mw && chain_mw_gave_up(ctx))) break;  // see rollout_impl
   }
-  NK_HIP(hipStreamSynchronize(ctx->stream));
   if (small) small_finish(st);
   return NK_OK;
 }

@@ -289,6 +289,13 @@ int launch_ref_minus_traj(nk_ctx* ctx, const double* ref, int64_t ref_stride, co
                           double* D, int64_t d_stride, int steps, int m, int batch);
 bool lifted_chain_ok(int m, int pu, int d_lift);
 int launch_lifted_chain(nk_ctx* ctx, const ChainArgs& a);
+// m > 128: multi-workgroup recursion, one launch per group of trajectories that is resident at once (nk_rollout.hip)
+bool lifted_chain_mw_ok(const nk_ctx* ctx, int m, int pu);
+int chain_mw_workgroups(int m);
+int launch_lifted_chain_mw(nk_ctx* ctx, const ChainArgs& a);
+int lifted_chain_mw_reset(nk_ctx* ctx);                                       // clears the device status words
+int lifted_chain_mw_fetch_status(nk_ctx* ctx);                                // queues their copy to the host
+bool lifted_chain_mw_timed_out(nk_ctx* ctx, int* row, int* step, int* traj);  // after the stream has been synchronised
 
 }  // namespace nk
 

@@ -164,11 +164,12 @@ def _fitted(nk, O, n=500, d=12, p=2, m=48, seed=3, ls=4.0, gamma=1e-4):
     return reg, ref, X, Y, rng
 
 
-@pytest.mark.parametrize("m,p", [(48, 2), (100, 6), (128, 6), (129, 3), (200, 1), (33, 0)])
+@pytest.mark.parametrize("m,p", [(48, 2), (100, 6), (128, 6), (129, 3), (200, 1), (33, 0), (520, 6), (1100, 2)])
 def test_rollout_single_launch_and_stepwise_paths(nk, O, m, p):
-    """m <= 128: the whole recursion (and the lift) in one launch with [A | B] resident in LDS; larger m: one launch per
-    step.  Both against the oracle's loop on the SAME operators (so that only the recursion is under test), single and
-    batched, with and without the lifted trajectory."""
+    """m <= 128: the whole recursion (and the lift) in one launch with [A | B] resident in the registers of one workgroup;
+    larger m: one launch as well, [A | B] spread over ceil(m / 8) workgroups that exchange the state through memory
+    (lifted_chain_mw_kernel).  Both against the oracle's loop on the SAME operators (so that only the recursion is under
+    test), single and batched, with and without the lifted trajectory."""
     reg, ref, X, Y, rng = _fitted(nk, O, n=max(4 * m, 300), d=9, p=p, m=m, seed=m + p)
     d = Y.shape[1]
     T = 40
@@ -196,6 +197,32 @@ def test_rollout_single_launch_and_stepwise_paths(nk, O, m, p):
     # T = 1: only the lifted initial state
     one = reg.rollout(X[3, :d], Useq[:, :1])
     assert relf(one, reg.C @ z0) < 1e-12
+    if m in (129, 200):  # more trajectories than the single-launch recursion takes: one GEMM per step
+        nb = 70
+        Ubig = rng.standard_normal((nb, 12, p))
+        big = reg.rollout(X[:nb, :d], Ubig)
+        for b in (0, 33, 69):
+            so, _ = O.rollout(reg.A, B, reg.C, reg.lift(X[b, :d].reshape(-1, 1)), Ubig[b].T)
+            assert relf(big[b].T, so) < 1e-11
+
+
+def test_rollout_multi_workgroup_recursion_repeats_stepwise_when_it_gives_up(nk, O, monkeypatch):
+    """m > 128: if a wave of the single-launch recursion gives up waiting for its neighbours (oversubscribed device) the
+    call repeats the recursion with one launch per step.  The hook makes the library take that branch."""
+    reg, ref, X, Y, rng = _fitted(nk, O, n=900, d=9, p=3, m=200, seed=21)
+    d, T = Y.shape[1], 25
+    Ub = rng.standard_normal((3, T, 3))
+    first = reg.rollout(X[:3, :d], Ub)
+    monkeypatch.setenv("NYSKOOP_CHAIN_MW_TEST_GIVEUP", "1")
+    again = reg.rollout(X[:3, :d], Ub)
+    K = reg.solve_lqr(c=0.5)
+    f0 = reg.lift(X[:2, :d].T).T
+    xs_step, us_step = reg.closed_loop(K, f0, f0[::-1].copy(), 15)
+    monkeypatch.delenv("NYSKOOP_CHAIN_MW_TEST_GIVEUP")
+    xs, us = reg.closed_loop(K, f0, f0[::-1].copy(), 15)
+    assert relf(again, first) < 1e-12 and relf(xs_step, xs) < 1e-12 and relf(us_step, us) < 1e-11
+    so, _ = O.rollout(reg.A, reg.B, reg.C, reg.lift(X[1, :d].reshape(-1, 1)), Ub[1].T)
+    assert relf(again[1].T, so) < 1e-11
 
 
 def test_rollout_vs_reference_golden_through_single_launch(nk, golden):
