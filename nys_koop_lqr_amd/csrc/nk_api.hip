@@ -1403,62 +1403,6 @@ static int model_wait_unchecked(nk_model* mdl) {
   return NK_OK;
 }
 
-int nk_lift(nk_ctx* ctx, const nk_model* mdl, const double* Xq, int64_t ldx, int64_t nq, double* out, int64_t ldo) {
-  NK_TRY(check_ctx(ctx));
-  NK_REQUIRE(mdl && Xq && out, "nk_lift: null argument");
-  NK_REQUIRE(nq >= 0 && ldx >= mdl->d && ldo >= mdl->m, "nk_lift: bad sizes");
-  if (nq == 0) return NK_OK;
-  MatIn x;
-  NK_TRY(stage_in(ctx, Xq, ldx, nq, mdl->d, &x));
-  MatOut o;
-  NK_TRY(stage_out(ctx, out, ldo, nq, mdl->m, &o));
-  NK_TRY(lift_device(ctx, mdl, x.ptr, x.ld, nq, o.dev, o.ld));
-  NK_TRY(finish_out(ctx, o));
-  NK_HIP(hipStreamSynchronize(ctx->stream));
-  return NK_OK;
-}
-
-int nk_predict(nk_ctx* ctx, const nk_model* mdl, const double* Xaug, int64_t ldx, int64_t nq, double* out,
-               int64_t ldo) {
-  NK_TRY(check_ctx(ctx));
-  NK_REQUIRE(mdl && Xaug && out, "nk_predict: null argument");
-  NK_REQUIRE(mdl->has_ops, "nk_predict: model holds no fitted operators");
-  NK_REQUIRE(nq >= 0 && ldx >= mdl->d + mdl->p && ldo >= mdl->d, "nk_predict: bad sizes");
-  if (nq == 0) return NK_OK;
-  MatIn x;
-  NK_TRY(stage_in(ctx, Xaug, ldx, nq, mdl->d + mdl->p, &x));
-  MatOut o;
-  NK_TRY(stage_out(ctx, out, ldo, nq, mdl->d, &o));
-  NK_TRY(predict_device(ctx, mdl, x.ptr, x.ld, nq, o.dev, o.ld));
-  NK_TRY(finish_out(ctx, o));
-  NK_HIP(hipStreamSynchronize(ctx->stream));
-  return NK_OK;
-}
-
-int nk_score_neg_rmse(nk_ctx* ctx, const nk_model* mdl, const double* Xaug, int64_t ldx, const double* Ytrue,
-                      int64_t ldy, int64_t nq, double* score) {
-  NK_TRY(check_ctx(ctx));
-  NK_REQUIRE(mdl && Xaug && Ytrue && score, "nk_score_neg_rmse: null argument");
-  NK_REQUIRE(mdl->has_ops, "nk_score_neg_rmse: model holds no fitted operators");
-  NK_REQUIRE(nq > 0 && ldx >= mdl->d + mdl->p && ldy >= mdl->d, "nk_score_neg_rmse: bad sizes");
-  const int d = mdl->d;
-  MatIn x, y;
-  NK_TRY(stage_in(ctx, Xaug, ldx, nq, d + mdl->p, &x));
-  NK_TRY(stage_in(ctx, Ytrue, ldy, nq, d, &y));
-  double *P = nullptr, *colsum = nullptr;
-  NK_TRY(arena_alloc_t(ctx, (size_t)nq * d, &P));
-  NK_TRY(arena_alloc_t(ctx, (size_t)d, &colsum));
-  NK_TRY(predict_device(ctx, mdl, x.ptr, x.ld, nq, P, d));
-  NK_TRY(launch_colsum_sqdiff(ctx, P, d, y.ptr, y.ld, nq, d, colsum));
-  std::vector<double> h((size_t)d);
-  NK_HIP(hipMemcpyAsync(h.data(), colsum, sizeof(double) * d, hipMemcpyDeviceToHost, ctx->stream));
-  NK_HIP(hipStreamSynchronize(ctx->stream));
-  double s = 0.0;
-  for (int j = 0; j < d; ++j) s += std::sqrt(h[j] / (double)nq);
-  *score = -s / d;
-  return NK_OK;
-}
-
 // ---- small-call staging: the latency-bound entry points (rollouts, closed loops) read their host inputs from, and write
 //      their host outputs into, one page-locked block that the GPU addresses directly -- no DMA descriptors, no staging
 //      copies on the stream; the host moves the bytes with memcpy before the launch and after the one synchronisation.
@@ -1495,6 +1439,97 @@ static void small_finish(SmallStage& st) {  // after the stream has been synchro
     for (int64_t r = 0; r < o.rows; ++r) memcpy(o.user + r * o.user_ld, o.stage + r * o.cols, (size_t)o.cols * 8);
 }
 static inline size_t pad256(size_t doubles) { return ((doubles * 8) + 255) & ~(size_t)255; }
+
+int nk_lift(nk_ctx* ctx, const nk_model* mdl, const double* Xq, int64_t ldx, int64_t nq, double* out, int64_t ldo) {
+  NK_TRY(check_ctx(ctx));
+  NK_REQUIRE(mdl && Xq && out, "nk_lift: null argument");
+  NK_REQUIRE(nq >= 0 && ldx >= mdl->d && ldo >= mdl->m, "nk_lift: bad sizes");
+  if (nq == 0) return NK_OK;
+  // a few states (one per tick of a controller that closes the loop on a plant, benchmark_lqr_hjb.py:73-97): through the
+  // page-locked block, no hipMemcpy of pageable memory (whose completion wait alone costs 30-100 us, depending on how
+  // the runtime decides to wait)
+  const size_t need = pad256((size_t)nq * mdl->d) + pad256((size_t)nq * mdl->m);
+  if (need <= SMALL_STAGE_LIMIT && !is_device_ptr(Xq) && !is_device_ptr(out)) {
+    SmallStage st;
+    st.ctx = ctx;
+    NK_TRY(small_reserve(ctx, need));
+    const double* xh = small_in(st, Xq, ldx, nq, mdl->d);
+    double* oh = small_out(st, out, ldo, nq, mdl->m);
+    double* xd = nullptr;  // every wave of the kernel-matrix kernel reads its state row: from HBM, not over PCIe
+    NK_TRY(arena_alloc_t(ctx, (size_t)nq * mdl->d, &xd));
+    NK_TRY(launch_copy2d(ctx, xh, mdl->d, xd, mdl->d, nq, mdl->d));
+    NK_TRY(lift_device(ctx, mdl, xd, mdl->d, nq, oh, mdl->m));
+    NK_HIP(hipStreamSynchronize(ctx->stream));
+    small_finish(st);
+    return NK_OK;
+  }
+  MatIn x;
+  NK_TRY(stage_in(ctx, Xq, ldx, nq, mdl->d, &x));
+  MatOut o;
+  NK_TRY(stage_out(ctx, out, ldo, nq, mdl->m, &o));
+  NK_TRY(lift_device(ctx, mdl, x.ptr, x.ld, nq, o.dev, o.ld));
+  NK_TRY(finish_out(ctx, o));
+  NK_HIP(hipStreamSynchronize(ctx->stream));
+  return NK_OK;
+}
+
+int nk_predict(nk_ctx* ctx, const nk_model* mdl, const double* Xaug, int64_t ldx, int64_t nq, double* out,
+               int64_t ldo) {
+  NK_TRY(check_ctx(ctx));
+  NK_REQUIRE(mdl && Xaug && out, "nk_predict: null argument");
+  NK_REQUIRE(mdl->has_ops, "nk_predict: model holds no fitted operators");
+  NK_REQUIRE(nq >= 0 && ldx >= mdl->d + mdl->p && ldo >= mdl->d, "nk_predict: bad sizes");
+  if (nq == 0) return NK_OK;
+  const int64_t dp = mdl->d + mdl->p;
+  const size_t need = pad256((size_t)nq * dp) + pad256((size_t)nq * mdl->d);
+  if (need <= SMALL_STAGE_LIMIT && !is_device_ptr(Xaug) && !is_device_ptr(out)) {  // see nk_lift
+    SmallStage st;
+    st.ctx = ctx;
+    NK_TRY(small_reserve(ctx, need));
+    const double* xh = small_in(st, Xaug, ldx, nq, dp);
+    double* oh = small_out(st, out, ldo, nq, mdl->d);
+    const int64_t ldd = dp + (dp & 1);
+    double* xd = nullptr;
+    NK_TRY(arena_alloc_t(ctx, (size_t)nq * ldd, &xd));
+    NK_TRY(launch_copy2d(ctx, xh, dp, xd, ldd, nq, dp));
+    NK_TRY(predict_device(ctx, mdl, xd, ldd, nq, oh, mdl->d));
+    NK_HIP(hipStreamSynchronize(ctx->stream));
+    small_finish(st);
+    return NK_OK;
+  }
+  MatIn x;
+  NK_TRY(stage_in(ctx, Xaug, ldx, nq, mdl->d + mdl->p, &x));
+  MatOut o;
+  NK_TRY(stage_out(ctx, out, ldo, nq, mdl->d, &o));
+  NK_TRY(predict_device(ctx, mdl, x.ptr, x.ld, nq, o.dev, o.ld));
+  NK_TRY(finish_out(ctx, o));
+  NK_HIP(hipStreamSynchronize(ctx->stream));
+  return NK_OK;
+}
+
+int nk_score_neg_rmse(nk_ctx* ctx, const nk_model* mdl, const double* Xaug, int64_t ldx, const double* Ytrue,
+                      int64_t ldy, int64_t nq, double* score) {
+  NK_TRY(check_ctx(ctx));
+  NK_REQUIRE(mdl && Xaug && Ytrue && score, "nk_score_neg_rmse: null argument");
+  NK_REQUIRE(mdl->has_ops, "nk_score_neg_rmse: model holds no fitted operators");
+  NK_REQUIRE(nq > 0 && ldx >= mdl->d + mdl->p && ldy >= mdl->d, "nk_score_neg_rmse: bad sizes");
+  const int d = mdl->d;
+  MatIn x, y;
+  NK_TRY(stage_in(ctx, Xaug, ldx, nq, d + mdl->p, &x));
+  NK_TRY(stage_in(ctx, Ytrue, ldy, nq, d, &y));
+  double *P = nullptr, *colsum = nullptr;
+  NK_TRY(arena_alloc_t(ctx, (size_t)nq * d, &P));
+  NK_TRY(arena_alloc_t(ctx, (size_t)d, &colsum));
+  NK_TRY(predict_device(ctx, mdl, x.ptr, x.ld, nq, P, d));
+  NK_TRY(launch_colsum_sqdiff(ctx, P, d, y.ptr, y.ld, nq, d, colsum));
+  std::vector<double> h((size_t)d);
+  NK_HIP(hipMemcpyAsync(h.data(), colsum, sizeof(double) * d, hipMemcpyDeviceToHost, ctx->stream));
+  NK_HIP(hipStreamSynchronize(ctx->stream));
+  double s = 0.0;
+  for (int j = 0; j < d; ++j) s += std::sqrt(h[j] / (double)nq);
+  *score = -s / d;
+  return NK_OK;
+}
 
 // z_{t+1} = G [z_t; u_t] (+ bias) for t < T-1 on Zall ([b][t][m], row 0 of every trajectory already holds z_0 unless
 // `chain.lift`), then x = C z for every (b, t).  One launch for the recursion when G fits in LDS, a matrix-vector /

@@ -382,26 +382,55 @@ int launch_gemm_pair(nk_ctx* ctx, bool transA, bool transB, const GemmCall* call
 // Small products (lift of a few states, the product with C after a rollout, p-column blocks): the 128 x 128 engine
 // would put the whole problem on one or two CUs and take 20-30 us; here every 16 x 16 output tile is a workgroup, operands
 // addressed through (row, column) strides so that one kernel serves all four transposition cases.
+constexpr int GS_BK = 64;  // contraction slice per step
 __device__ __forceinline__ void gemm_small_kernel_body(int M, int N, int K, double alpha, const double* __restrict__ A, int64_t sai, int64_t sak, const double* __restrict__ B, int64_t sbk, int64_t sbj, double beta, double* __restrict__ C, int64_t ldc) {
-  __shared__ double As[16][17];
-  __shared__ double Bs[16][17];
-  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  // These products are latency bound (a lift of one state at m = 500 is 32 dependent global-load round trips with
+  // 16-wide slices: 22 us): 64-wide slices, the loads of slice s + 1 in flight while slice s is multiplied, and four
+  // accumulators per entry (k mod 4) instead of one 64-deep FMA chain.
+  __shared__ double As[16][GS_BK + 1];
+  __shared__ double Bs[GS_BK][17];
+  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
   const int i0 = blockIdx.y * 16, j0 = blockIdx.x * 16;
-  double acc = 0.0;
-  for (int k0 = 0; k0 < K; k0 += 16) {
-    const int ia = i0 + ty, ka = k0 + tx;
-    As[ty][tx] = (ia < M && ka < K) ? A[(int64_t)ia * sai + (int64_t)ka * sak] : 0.0;
-    const int kb = k0 + ty, jb = j0 + tx;
-    Bs[ty][tx] = (kb < K && jb < N) ? B[(int64_t)kb * sbk + (int64_t)jb * sbj] : 0.0;
-    __syncthreads();
+  // element -> (row, k) assignment of the four loads per operand: the unit-stride direction is the fast one
+  const bool a_kfast = sak == 1, b_jfast = sbj == 1;
+  int ai[4], ak[4], bk[4], bj[4];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) acc = fma(As[ty][k], Bs[k][tx], acc);
+  for (int q = 0; q < 4; ++q) {
+    const int e = tid + 256 * q;
+    ai[q] = a_kfast ? e >> 6 : e & 15;
+    ak[q] = a_kfast ? e & 63 : e >> 4;
+    bk[q] = b_jfast ? e >> 4 : e & 63;
+    bj[q] = b_jfast ? e & 15 : e >> 6;
+  }
+  double ra[4], rb[4];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int ia = i0 + ai[q], ka = k0 + ak[q];
+      ra[q] = (ia < M && ka < K) ? A[(int64_t)ia * sai + (int64_t)ka * sak] : 0.0;
+      const int kb = k0 + bk[q], jb = j0 + bj[q];
+      rb[q] = (kb < K && jb < N) ? B[(int64_t)kb * sbk + (int64_t)jb * sbj] : 0.0;
+    }
+  };
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  fetch(0);
+  for (int k0 = 0; k0 < K; k0 += GS_BK) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      As[ai[q]][ak[q]] = ra[q];
+      Bs[bk[q]][bj[q]] = rb[q];
+    }
+    __syncthreads();
+    if (k0 + GS_BK < K) fetch(k0 + GS_BK);  // in flight during the products below
+#pragma unroll
+    for (int k = 0; k < GS_BK; ++k) acc[k & 3] = fma(As[ty][k], Bs[k][tx], acc[k & 3]);
     __syncthreads();
   }
   const int i = i0 + ty, j = j0 + tx;
   if (i < M && j < N) {
+    const double sum = (acc[0] + acc[1]) + (acc[2] + acc[3]);
     double* c = C + (int64_t)i * ldc + j;
-    *c = (beta == 0.0) ? alpha * acc : fma(alpha, acc, beta * *c);
+    *c = (beta == 0.0) ? alpha * sum : fma(alpha, sum, beta * *c);
   }
 }
 __global__ void __launch_bounds__(256) gemm_small_kernel(int M, int N, int K, double alpha, const double* __restrict__ A, int64_t sai, int64_t sak, const double* __restrict__ B, int64_t sbk, int64_t sbj, double beta, double* __restrict__ C, int64_t ldc) { gemm_small_kernel_body(M, N, K, alpha, A, sai, sak, B, sbk, sbj, beta, C, ldc); }

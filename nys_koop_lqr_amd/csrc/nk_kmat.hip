@@ -20,6 +20,7 @@ constexpr int KSTRIDE = 128; // doubles per LDS row
 
 template <int KTYPE>
 __device__ __forceinline__ double kmat_epilogue(double acc, double sigma0sq) {
+#pragma clang fp contract(off)  // the same operations in every kernel that inlines this (bits do not depend on the shape)
   if (KTYPE == NK_KERNEL_RBF) {
     return exp(-0.5 * acc);
   } else if (KTYPE == NK_KERNEL_MATERN52) {
@@ -150,6 +151,7 @@ template <int KTYPE>
 __device__ __forceinline__ void kmat_flat_body(const double* __restrict__ A, int64_t lda, int64_t nA, const double* __restrict__ B,
                                                int64_t ldb, int nB, int d, const double* __restrict__ winv, double sigma0sq,
                                                double* __restrict__ out, int64_t ldo, int64_t step_i, int step_j) {
+#pragma clang fp contract(off)  // (a w) - (b w) with both products rounded, as in the tiled kernel: same bits
   extern __shared__ __attribute__((aligned(16))) double kf_lds[];
   double* Bs = kf_lds;          // nB x d, pre-scaled
   double* ws = Bs + (size_t)nB * d;
@@ -212,6 +214,95 @@ __global__ void __launch_bounds__(256) kmat_flat_kernel_batched(
       "kmat_flat_kernel<" #K ">");
 NK_KFLAT_TWIN(0) NK_KFLAT_TWIN(1) NK_KFLAT_TWIN(2)
 
+// ---------------------------------------------------------------------------------------------------------------
+// A handful of entries (the lift or prediction of ONE state, regressors.py:171-178 inside a control loop; K(Z, Z) at
+// tiny m): latency is all that matters and the tiled kernel would run in one or two workgroups whose threads mostly hold
+// padding (71 us for a 1 x 100 row at d = 192).  One WAVE per entry: the 64 lanes fetch 64 consecutive dimensions of the
+// two rows (coalesced) and form the scaled differences, then the sum over the dimensions is accumulated IN INDEX ORDER by
+// a chain of FMAs whose operands are broadcast from lane q = 0, 1, ... by v_readlane (uniform, every lane runs the same
+// chain).  Per entry that is, operation by operation, the arithmetic of the tiled kernel (products with 1/lengthscale
+// rounded separately, difference, FMA over the dimensions in index order; padding adds exact zeros), hence the same
+// bits whichever kernel a shape selects.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int64_t KSMALL_MAX_ENTRIES = 8192;
+__device__ __forceinline__ double readlane_f64(double v, int q) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), q);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), q);
+  return __hiloint2double(hi, lo);
+}
+template <int KTYPE>
+__device__ __forceinline__ void kmat_small_body(const double* __restrict__ A, int64_t lda, int nA, const double* __restrict__ B,
+                                                int64_t ldb, int nB, int d, const double* __restrict__ winv, double sigma0sq,
+                                                double* __restrict__ out, int64_t ldo) {
+#pragma clang fp contract(off)  // a w - b w must not become fma(a, w, -(b w)): K(Z, Z) is bitwise symmetric
+  const int lane = threadIdx.x & 63;
+  const int64_t e = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (e >= (int64_t)nA * nB) return;  // wave-uniform
+  const int i = (int)(e / nB), j = (int)(e - (int64_t)i * nB);
+  const double* a = A + (int64_t)i * lda;
+  const double* b = B + (int64_t)j * ldb;
+  double acc = 0.0;
+  for (int k0 = 0; k0 < d; k0 += 64) {
+    const int k = k0 + lane;
+    double x = 0.0, y = 0.0;
+    if (k < d) {
+      const double w = winv[k];
+      x = a[k] * w;
+      y = b[k] * w;
+    }
+    const int cnt = d - k0 < 64 ? d - k0 : 64;
+    if (KTYPE == NK_KERNEL_LINEAR) {
+      int q = 0;
+      for (; q + 8 <= cnt; q += 8) {
+        double sx[8], sy[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { sx[u] = readlane_f64(x, q + u); sy[u] = readlane_f64(y, q + u); }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = fma(sx[u], sy[u], acc);
+      }
+      for (; q < cnt; ++q) acc = fma(readlane_f64(x, q), readlane_f64(y, q), acc);
+    } else {
+      const double df = x - y;
+      int q = 0;
+      for (; q + 8 <= cnt; q += 8) {  // the broadcasts of eight steps are independent of the chain: issued ahead of it
+        double s[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s[u] = readlane_f64(df, q + u);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = fma(s[u], s[u], acc);
+      }
+      for (; q < cnt; ++q) {
+        const double s = readlane_f64(df, q);
+        acc = fma(s, s, acc);
+      }
+    }
+  }
+  if (lane == 0) out[(int64_t)i * ldo + j] = kmat_epilogue<KTYPE>(acc, sigma0sq);
+}
+template <int KTYPE>
+__global__ void __launch_bounds__(256) kmat_small_kernel(const double* __restrict__ A, int64_t lda, int nA,
+                                                        const double* __restrict__ B, int64_t ldb, int nB, int d,
+                                                        const double* __restrict__ winv, double sigma0sq,
+                                                        double* __restrict__ out, int64_t ldo) {
+  kmat_small_body<KTYPE>(A, lda, nA, B, ldb, nB, d, winv, sigma0sq, out, ldo);
+}
+template <int KTYPE>
+__global__ void __launch_bounds__(256) kmat_small_kernel_batched(
+    const nk::ArgPack<const double*, int64_t, int, const double*, int64_t, int, int, const double*, double, double*, int64_t>* table) {
+  const nk::ArgPack<const double*, int64_t, int, const double*, int64_t, int, int, const double*, double, double*, int64_t> p =
+      table[blockIdx.z];
+  nk::pack_apply([](auto... a) { kmat_small_body<KTYPE>(a...); }, p);
+}
+#define NK_KSMALL_TWIN(K)                                                                                                    \
+  static nk::TwinReg ksmall_twin_reg_##K(                                                                                    \
+      reinterpret_cast<const void*>(static_cast<void (*)(const double*, int64_t, int, const double*, int64_t, int, int,      \
+                                                         const double*, double, double*, int64_t)>(kmat_small_kernel<K>)),   \
+      reinterpret_cast<const void*>(kmat_small_kernel_batched<K>),                                                           \
+      sizeof(nk::ArgPack<const double*, int64_t, int, const double*, int64_t, int, int, const double*, double, double*,      \
+                         int64_t>),                                                                                          \
+      "kmat_small_kernel<" #K ">");
+NK_KSMALL_TWIN(0) NK_KSMALL_TWIN(1) NK_KSMALL_TWIN(2)
+
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 int launch_kmat(nk_ctx* ctx, int ktype, const double* A, int64_t lda, int64_t nA, const double* B, int64_t ldb,
@@ -244,6 +335,20 @@ int launch_kmat(nk_ctx* ctx, int ktype, const double* A, int64_t lda, int64_t nA
     else
       hipLaunchKernelGGL((kmat_flat_kernel<NK_KERNEL_LINEAR>), g, dim3(256), lds, ctx->stream, A, lda, nA, B, ldb, (int)nB, d,
                          winv, s2, out, ldo, step_i, step_j);
+    NK_HIP(hipGetLastError());
+    return NK_OK;
+  }
+  if (nA * nB <= KSMALL_MAX_ENTRIES && ktype >= NK_KERNEL_RBF && ktype <= NK_KERNEL_LINEAR) {
+    const dim3 g((unsigned)((nA * nB + 3) / 4));  // one wave per entry
+    if (ktype == NK_KERNEL_RBF)
+      hipLaunchKernelGGL((kmat_small_kernel<NK_KERNEL_RBF>), g, dim3(256), 0, ctx->stream, A, lda, (int)nA, B, ldb, (int)nB, d,
+                         winv, s2, out, ldo);
+    else if (ktype == NK_KERNEL_MATERN52)
+      hipLaunchKernelGGL((kmat_small_kernel<NK_KERNEL_MATERN52>), g, dim3(256), 0, ctx->stream, A, lda, (int)nA, B, ldb,
+                         (int)nB, d, winv, s2, out, ldo);
+    else
+      hipLaunchKernelGGL((kmat_small_kernel<NK_KERNEL_LINEAR>), g, dim3(256), 0, ctx->stream, A, lda, (int)nA, B, ldb,
+                         (int)nB, d, winv, s2, out, ldo);
     NK_HIP(hipGetLastError());
     return NK_OK;
   }

@@ -132,6 +132,28 @@ __device__ __forceinline__ double reduce_4rows_32parts(double a0, double a1, dou
   return c;
 }
 
+// lanes 32-63 of a change places with lanes 0-31 of b
+__device__ __forceinline__ void swap32_f64(double& a, double& b) {
+  const chain_u2 lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+  const chain_u2 hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+  a = __hiloint2double((int)hi.x, (int)lo.x);
+  b = __hiloint2double((int)hi.y, (int)lo.y);
+}
+// sum of one value over the 64 lanes, in every lane, without the LDS crossbar (wave_sum64 above is six dependent
+// ds_bpermute round trips)
+__device__ __forceinline__ double wave_sum64_dpp(double c) {
+  c += dpp_f64<0xB1>(c);   // quad_perm [1,0,3,2]
+  c += dpp_f64<0x4E>(c);   // quad_perm [2,3,0,1]
+  c += dpp_f64<0x141>(c);  // row_half_mirror
+  c += dpp_f64<0x140>(c);  // row_mirror: every lane of a 16-lane row holds the row total
+  double a = c, b = c;
+  swap16_f64(a, b);
+  c = a + b;               // rows 0+1, 2+3
+  a = c; b = c;
+  swap32_f64(a, b);
+  return a + b;
+}
+
 __global__ void __launch_bounds__(CHAIN_THREADS) lifted_chain_kernel(ChainParams P) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int m = P.m, pu = P.pu, mpu = m + pu;
@@ -345,7 +367,7 @@ __global__ void __launch_bounds__(64 * MW_ROWS) lifted_chain_mw_kernel(ChainMwPa
       if (j & 1) a1 = fma(g[j], v, a1);
       else a0 = fma(g[j], v, a0);
     }
-    const double acc = wave_sum64(a0 + a1);
+    const double acc = wave_sum64_dpp(a0 + a1);
     if (active && lane == 0) {
       unsigned long long out = (unsigned long long)__double_as_longlong(acc + bias);
       if (out == MW_SENTINEL) out = MW_QNAN;

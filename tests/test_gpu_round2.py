@@ -492,3 +492,19 @@ def test_lockstep_pool_runs_ordinary_api_calls(nk, O):
     for got in pool.map(unit, range(8)):  # a full round of 5 and a partial round of 3
         for a, b in zip(got, want):
             assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("family", [0, 1, 2])
+@pytest.mark.parametrize("d", [2, 21, 192])
+def test_kernel_matrix_bits_do_not_depend_on_the_shape(nk, family, d):
+    """The three kernel-matrix kernels (tiled, flat streaming for d <= 8, one thread per entry for a handful of entries --
+    the lift of ONE state inside a control loop) do the same operations per entry in the same order: a row of a big call
+    and the same row computed alone have the same bits."""
+    rng = np.random.default_rng(100 * family + d)
+    A = rng.standard_normal((700, d)); B = rng.standard_normal((150, d))
+    ls = rng.uniform(0.5, 3.0, size=d) * np.sqrt(d)
+    k = nk.kernels.DeviceKernel(family, ls) if family < 2 else nk.LinearKernelWrapper(0.7).kernel
+    big = k(A, B)                      # 105 000 entries: tiled (or flat at d = 2)
+    for rows in (slice(0, 1), slice(3, 8), slice(650, 700)):
+        assert np.array_equal(k(A[rows], B), big[rows])   # <= 7500 entries: one thread per entry
+    assert np.array_equal(k(A[:40], B[:7]), big[:40, :7])

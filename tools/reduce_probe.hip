@@ -30,6 +30,26 @@ __device__ __forceinline__ double reduce_4rows_32parts(double a0, double a1, dou
   c += dpp_f64<0x141>(c);                  // row_half_mirror
   return c;
 }
+__device__ __forceinline__ void swap32_f64(double& a, double& b) {
+  const u2 lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+  const u2 hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+  a = __hiloint2double((int)hi.x, (int)lo.x);
+  b = __hiloint2double((int)hi.y, (int)lo.y);
+}
+// sum of one value over the 64 lanes, in every lane
+__device__ __forceinline__ double wave_sum64_dpp(double c) {
+  c += dpp_f64<0xB1>(c);
+  c += dpp_f64<0x4E>(c);
+  c += dpp_f64<0x141>(c);
+  c += dpp_f64<0x140>(c);
+  double a = c, b = c;
+  swap16_f64(a, b);
+  c = a + b;
+  a = c; b = c;
+  swap32_f64(a, b);
+  return a + b;
+}
+__global__ void k2(const double* in, double* out) { out[threadIdx.x] = wave_sum64_dpp(in[threadIdx.x * 4]); }
 __global__ void k(const double* in, double* out) {  // in[lane][4], out[lane]
   const int lane = threadIdx.x;
   out[lane] = reduce_4rows_32parts(in[lane * 4], in[lane * 4 + 1], in[lane * 4 + 2], in[lane * 4 + 3], lane);
@@ -49,5 +69,13 @@ int main() {
     if (std::fabs(ref - o[lane]) > 1e-9) { ++bad; printf("lane %d row %d: got %g want %g\n", lane, r, o[lane], ref); }
   }
   printf(bad ? "reduce_probe: %d lanes WRONG\n" : "reduce_probe: all 64 lanes correct\n", bad);
-  return bad != 0;
+  k2<<<1, 64>>>(d, dout);
+  hipMemcpy(o, dout, sizeof(o), hipMemcpyDeviceToHost);
+  double tot = 0.0;
+  for (int lane = 0; lane < 64; ++lane) tot += h[lane * 4];
+  int bad2 = 0;
+  for (int lane = 0; lane < 64; ++lane)
+    if (std::fabs(o[lane] - tot) > 1e-9) { ++bad2; printf("wave sum lane %d: got %g want %g\n", lane, o[lane], tot); }
+  printf(bad2 ? "wave_sum64_dpp: %d lanes WRONG\n" : "wave_sum64_dpp: all 64 lanes correct\n", bad2);
+  return bad != 0 || bad2 != 0;
 }
