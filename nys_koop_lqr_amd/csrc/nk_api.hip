@@ -414,6 +414,7 @@ int nk_create(int device, nk_ctx** out) {
   ctx->h_piv = reinterpret_cast<unsigned long long*>(ctx->h_info + 16);
   for (int i = 0; i < 16; ++i) NK_HIP(hipEventCreate(&ctx->ev[i]));
   NK_HIP(hipEventCreateWithFlags(&ctx->ev_ext, hipEventDisableTiming));
+  for (int i = 0; i < 8; ++i) NK_HIP(hipEventCreateWithFlags(&ctx->ev_up[i], hipEventDisableTiming));
   const char* km = getenv("NYSKOOP_KMAT");
   ctx->kmat_mode = (km && strcmp(km, "direct") == 0) ? 1 : 0;
   const char* st = getenv("NYSKOOP_STRICT_SPD");
@@ -439,6 +440,7 @@ static void destroy_ctx_unregistered(nk_ctx* ctx) {
   (void)hipEventDestroy(ctx->ev_fork);
   (void)hipEventDestroy(ctx->ev_join);
   if (ctx->ev_ext) (void)hipEventDestroy(ctx->ev_ext);
+  for (int i = 0; i < 8; ++i) if (ctx->ev_up[i]) (void)hipEventDestroy(ctx->ev_up[i]);
   (void)hipStreamDestroy(ctx->stream_side);
   (void)hipStreamDestroy(ctx->stream_prep);
   (void)hipStreamDestroy(ctx->stream_copy);
@@ -777,7 +779,25 @@ static int fit_impl(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int6
   NK_HIP(hipEventRecord(ev[0], ctx->stream));
   NK_TRY(make_winv(ctx, kd, d, mdl->winv));
   MatIn x, y, zi, zo;
+  // Large HOST arrays (how the reference's fit(X, Y) is called: 620 MB at the headline shape, ~11 ms of PCIe): the rows
+  // are uploaded in `host_passes` blocks on the side stream, block k + 1 while the kernel blocks and the Gram launch of
+  // block k run (the contraction is accumulated over passes anyway, below).  Only the first block's upload is exposed.
+  int host_passes = 1;
   if (mode != FIT_SOLVE) {
+    const char* e = getenv("NYSKOOP_HOST_PASSES");
+    const int want = e ? atoi(e) : 4;
+    if (want > 1 && rng.size() == 2 && !ctx_recording(ctx) && (double)n_eff * (2.0 * d + p) * 8.0 >= 64e6 &&
+        !is_device_ptr(X) && !is_device_ptr(Y))
+      host_passes = want > 8 ? 8 : want;
+  }
+  if (mode != FIT_SOLVE && host_passes > 1) {
+    x.ld = (d + p + 1) & ~(int64_t)1;
+    y.ld = (d + 1) & ~(int64_t)1;
+    double *xd = nullptr, *yd = nullptr;
+    NK_TRY(arena_alloc_t(ctx, (size_t)n * x.ld, &xd));
+    NK_TRY(arena_alloc_t(ctx, (size_t)n * y.ld, &yd));
+    x.ptr = xd; y.ptr = yd; x.staged = y.staged = true;
+  } else if (mode != FIT_SOLVE) {
     NK_TRY(stage_in(ctx, X, ldx, n, d + p, &x));
     NK_TRY(stage_in(ctx, Y, ldy, n, d, &y));
   }
@@ -856,6 +876,10 @@ static int fit_impl(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int6
     const double budget = (b ? atof(b) : 48.0) * 1073741824.0;
     pass_rows = (int64_t)(budget / ((double)ldf * 8.0));
     if (pass_rows < 1024) pass_rows = 1024;
+    if (host_passes > 1) {  // pipelined upload: at least `host_passes` passes (more if the workspace budget says so)
+      const int64_t per = ((n_eff + host_passes - 1) / host_passes + 1023) & ~(int64_t)1023;
+      if (per < pass_rows) pass_rows = per;
+    }
   }
   struct Piece { int64_t b, len; };
   std::vector<std::vector<Piece>> passes(1);
@@ -906,9 +930,28 @@ static int fit_impl(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int6
     }
   }
   const bool multi_pass = passes.size() > 1;
+  const bool pipelined = host_passes > 1;
+  // upload of the rows of pass ip from the caller's host arrays, on the side stream (the call blocks the HOST while the
+  // runtime moves pageable memory through its bounce buffers; the device works on the previous pass meanwhile)
+  auto upload_pass = [&](size_t ip) -> int {
+    for (const Piece& pc : passes[ip]) {
+      NK_HIP(hipMemcpy2DAsync(const_cast<double*>(x.ptr) + pc.b * x.ld, (size_t)x.ld * 8, X + pc.b * ldx, (size_t)ldx * 8,
+                              (size_t)(d + p) * 8, (size_t)pc.len, hipMemcpyHostToDevice, ctx->stream_side));
+      NK_HIP(hipMemcpy2DAsync(const_cast<double*>(y.ptr) + pc.b * y.ld, (size_t)y.ld * 8, Y + pc.b * ldy, (size_t)ldy * 8,
+                              (size_t)d * 8, (size_t)pc.len, hipMemcpyHostToDevice, ctx->stream_side));
+    }
+    NK_HIP(hipEventRecord(ctx->ev_up[ip & 7], ctx->stream_side));
+    return NK_OK;
+  };
+  if (pipelined) {
+    NK_HIP(hipEventRecord(ev[12], ctx->stream));  // the side stream starts after whatever the main stream has queued
+    NK_HIP(hipStreamWaitEvent(ctx->stream_side, ev[12], 0));
+    NK_TRY(upload_pass(0));
+  }
   for (size_t ip = 0; ip < passes.size(); ++ip) {
     const std::vector<Piece>& ps = passes[ip];
     const double beta = ip == 0 ? 0.0 : 1.0;
+    if (pipelined) NK_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_up[ip & 7], 0));
     // -- kernel blocks of this pass
     int64_t o = 0;
     for (const Piece& pc : ps) {
@@ -966,7 +1009,8 @@ static int fit_impl(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int6
     if (fast) {
       const int np = (single && fast_y) ? 4 : 3;
       float ms1 = 0.f;
-      NK_TRY(launch_gemm_tn_multi(ctx, pr, np, rows, 0, timed ? &ms1 : nullptr, multi_pass));
+      // (pipelined uploads: no per-launch timing, it would make the host wait for the launch before the next upload)
+      NK_TRY(launch_gemm_tn_multi(ctx, pr, np, rows, 0, (timed && !pipelined) ? &ms1 : nullptr, multi_pass));
       if (multi_pass) ms_gram_kernel += ms1; else gram_deferred = timed;
       gram_launches += 1;
       y_done = np == 4;
@@ -992,6 +1036,7 @@ static int fit_impl(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int6
         first = false;
       }
     }
+    if (pipelined && ip + 1 < passes.size()) NK_TRY(upload_pass(ip + 1));
   }
   }  // mode != FIT_SOLVE
   NK_HIP(hipEventRecord(ev[3], ctx->stream));

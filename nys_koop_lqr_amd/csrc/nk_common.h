@@ -82,6 +82,7 @@ struct nk_ctx {
   int strict_spd = 0; // 1: a non-positive Cholesky pivot is an error (NK_ERR_NOT_SPD) instead of entering the
                       // rank-truncating pseudo-inverse path (NYSKOOP_STRICT_SPD=1 / nk_set_strict_spd)
   hipEvent_t ev_ext = nullptr;  // ordering against a caller's stream (nk_wait_stream)
+  hipEvent_t ev_up[8] = {};     // uploads of the row blocks of a fit from host arrays (pipelined with the passes)
   nk_group* group = nullptr;    // member of a lock-step group (nk_lockstep.h): stream operations are recorded and merged
   nk_member_state* gstate = nullptr;
   double* h_stage = nullptr;    // page-locked, device-visible staging block for the small latency-bound calls (rollouts):
