@@ -145,7 +145,7 @@ def cv_sweep_rate(nk, workers=4):
     cands = [dict(kernel=nk.ThreeDimensionalKernel(l, l, l, d), gamma=g, m=m) for l in (3.0, 6.0, 12.0)
              for g in (1e-6, 1e-5, 1e-4)]
     centers = {(c, f): np.random.RandomState(17 * c + f).choice(808, m, replace=False) for c in range(9) for f in range(5)}
-    cands = cands * 4  # 180 units
+    cands = cands * 9  # 81 candidates x 5 folds = 405 units, the size of the reference's grid (benchmark_lqr_cloth.py:46-57)
     centers = {(c, f): np.random.RandomState(17 * c + f).choice(808, m, replace=False) for c in range(len(cands))
                for f in range(5)}
     nu = len(cands) * 5
@@ -155,7 +155,7 @@ def cv_sweep_rate(nk, workers=4):
     dt1 = time.perf_counter() - t0
     harness.grid_search_cv(X, Y, p, cands, centers=centers, batch=30, batch_groups=3)  # warm-up of every group member
     dt = 1e9
-    for _ in range(2):
+    for _ in range(3):
         t0 = time.perf_counter()
         res = harness.grid_search_cv(X, Y, p, cands, centers=centers, batch=30, batch_groups=3)
         dt = min(dt, time.perf_counter() - t0)
@@ -246,6 +246,11 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    # as `timeit` does: no cyclic garbage collection inside the timed region (a full CPython collection walks the ~1e6
+    # objects NumPy / SciPy / torch keep alive and takes 45-75 ms here, tools/gc_probe.py -- more than one fit)
+    import gc
+    gc.collect()
+    gc.disable()
     t0 = time.perf_counter()
     stats = []
     if conc > 1:
@@ -265,6 +270,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -14,7 +14,12 @@ done
 cd $R
 python3 tools/lockstep_bench.py 16 64 32x2 30x3 > $O/lockstep_bench.log 2>&1
 python3 tools/rollout_bench.py > $O/rollout_bench.log 2>&1
+python3 tools/lift_latency.py >> $O/rollout_bench.log 2>&1
+python3 tools/chain_mw_probe.py 500,6,6 1000,8,3 2000,8,6 > $O/chain_mw_probe.log 2>&1
+NYSKOOP_CHAIN_MW=0 python3 tools/chain_mw_probe.py 500,6,6 2000,8,6 > $O/chain_mw_probe_stepwise.log 2>&1
+NYSKOOP_HOST_PASSES=1 python3 tools/host_fit_bench.py > $O/host_fit_bench.log 2>&1
+python3 tools/host_fit_bench.py >> $O/host_fit_bench.log 2>&1
 python3 tools/cv_bench.py > $O/cv_bench.log 2>&1
 python3 tools/soak.py 30 > $O/soak.log 2>&1
 python3 tools/shape_sweep.py 32 > $O/shape_sweep.log 2>&1
-tail -4 $O/lockstep_bench.log | cut -c1-150; tail -4 $O/rollout_bench.log | cut -c1-200; tail -3 $O/soak.log; tail -3 $O/shape_sweep.log
+tail -4 $O/lockstep_bench.log | cut -c1-150; grep "^m=" $O/rollout_bench.log | cut -c1-300; grep PASSES $O/host_fit_bench.log; tail -3 $O/soak.log; tail -3 $O/shape_sweep.log
