@@ -316,7 +316,8 @@ __global__ void mw_sentinel_fill_kernel(double* __restrict__ Zall, int64_t z_str
 }
 
 // KPT = number of 64-wide chunks of z_t (compile time: the LDS reads and FMAs of a step are straight-line code).  The
-// chunk past m re-reads z[m - 1] and meets zeros of g.  The controls are a separate term: lane l < pu holds G[r][m + l].
+// chunk past m re-reads z[m - 1] (a valid address) and parks zeros.  The controls are a separate term: lane l < pu holds
+// G[r][m + l].
 template <int KPT>
 __global__ void __launch_bounds__(64 * MW_ROWS) lifted_chain_mw_kernel(ChainMwParams P) {
   __shared__ double zs[2][KPT * 64];
@@ -354,7 +355,7 @@ __global__ void __launch_bounds__(64 * MW_ROWS) lifted_chain_mw_kernel(ChainMwPa
           bits = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
-      buf[k] = __longlong_as_double((long long)bits);
+      buf[k] = k < m ? __longlong_as_double((long long)bits) : 0.0;  // (0 x an overflowed z[m - 1] would be NaN)
     }
     double a0 = (U != nullptr && lane < pu) ? gu * U[(int64_t)t * pu + lane] : 0.0;
     double a1 = 0.0;
