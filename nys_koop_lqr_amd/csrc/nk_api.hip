@@ -616,42 +616,86 @@ int nk_cv_grid(nk_ctx* const* members, int32_t n_members, const double* X, int64
       if (++arrived == parties) { arrived = 0; ++gen; lk.unlock(); cv.notify_all(); return; }
       cv.wait(lk, [&] { return gen != g; });
     }
-  } round;
-  const int n_rounds = (n_units + B - 1) / B;
-  auto worker = [&](int k) {
-    nk_ctx* ctx = members[k];
-    std::vector<double> Z;
-    for (int r = 0; r < n_rounds; ++r) {
-      const int u = r * B + k;
-      const bool mine = u < n_units;
-      if (mine) (void)group_enter(ctx);
-      round.wait(B);
-      if (mine) {
-        const nk_cv_unit& cu = units[u];
-        Z.resize((size_t)cu.m * d);
-        for (int j = 0; j < cu.m; ++j) memcpy(&Z[(size_t)j * d], Yh + cu.landmark_rows[j] * ldyh, (size_t)d * 8);
-        const int64_t rr[4] = {0, cu.test_begin, cu.test_end, n};
-        nk_model* mdl = nullptr;
-        int rc = nk_nystrom_fit(ctx, cu.kernel, Xd, ldxd, Yd, ldyd, n, d, p, rr, 2, nullptr, 0, Z.data(), d, cu.m, cu.gamma,
-                                cu.jitter, &mdl, nullptr);
-        double sc = std::nan("");
-        if (rc == NK_OK)
-          rc = nk_score_neg_rmse(ctx, mdl, Xd + cu.test_begin * ldxd, ldxd, Yd + cu.test_begin * ldyd, ldyd,
-                                 cu.test_end - cu.test_begin, &sc);
-        if (mdl) nk_model_destroy(mdl);
-        scores[u] = rc == NK_OK ? sc : std::nan("");
-        if (status) status[u] = rc;
-        tl_ctx = ctx;
-        (void)group_leave(ctx);
-      }
-      round.wait(B);
-    }
-    tl_ctx = nullptr;
   };
-  std::vector<std::thread> threads;
-  threads.reserve((size_t)B);
-  for (int k = 0; k < B; ++k) threads.emplace_back(worker, k);
-  for (auto& t : threads) t.join();
+  // Two phases.  A unit whose regularised system is numerically rank deficient takes gelsd's branch: a Jacobi SVD of ~1e4
+  // launches (0.2 s at m = 500) during which the other members of its round have nothing to merge with and wait at the
+  // next barrier -- a 405-unit cloth grid with 30 such units spent 2 of its 2.4 s that way.  So the first phase runs every
+  // unit in strict mode (the factorisation reports the condition and the unit stops there), and the units that reported
+  // it are run again TOGETHER in a second phase with the fallback enabled: their Jacobi sweeps merge into shared launches.
+  // Same kernels on the same data in both orders: the scores do not depend on the schedule.
+  std::vector<int> saved_strict((size_t)B);
+  for (int k = 0; k < B; ++k) saved_strict[(size_t)k] = members[k]->strict_spd;
+  std::mutex deferred_mu;
+  std::vector<int> deferred;
+  auto run_units = [&](const std::vector<int>& list, bool defer_rank_deficient) {
+    Round round;
+    const int count = (int)list.size();
+    const int n_rounds = (count + B - 1) / B;
+    auto worker = [&](int k) {
+      nk_ctx* ctx = members[k];
+      std::vector<double> Z;
+      for (int r = 0; r < n_rounds; ++r) {
+        const int slot = r * B + k;
+        const bool mine = slot < count;
+        if (mine) (void)group_enter(ctx);
+        round.wait(B);
+        if (mine) {
+          const int u = list[(size_t)slot];
+          const nk_cv_unit& cu = units[u];
+          Z.resize((size_t)cu.m * d);
+          for (int j = 0; j < cu.m; ++j) memcpy(&Z[(size_t)j * d], Yh + cu.landmark_rows[j] * ldyh, (size_t)d * 8);
+          const int64_t rr[4] = {0, cu.test_begin, cu.test_end, n};
+          nk_model* mdl = nullptr;
+          int rc = nk_nystrom_fit(ctx, cu.kernel, Xd, ldxd, Yd, ldyd, n, d, p, rr, 2, nullptr, 0, Z.data(), d, cu.m, cu.gamma,
+                                  cu.jitter, &mdl, nullptr);
+          double sc = std::nan("");
+          if (rc == NK_OK)
+            rc = nk_score_neg_rmse(ctx, mdl, Xd + cu.test_begin * ldxd, ldxd, Yd + cu.test_begin * ldyd, ldyd,
+                                   cu.test_end - cu.test_begin, &sc);
+          if (mdl) nk_model_destroy(mdl);
+          if (rc == NK_ERR_NOT_SPD && defer_rank_deficient) {
+            std::lock_guard<std::mutex> lk(deferred_mu);
+            deferred.push_back(u);
+          } else {
+            scores[u] = rc == NK_OK ? sc : std::nan("");
+            if (status) status[u] = rc;
+          }
+          tl_ctx = ctx;
+          (void)group_leave(ctx);
+        }
+        round.wait(B);
+      }
+      tl_ctx = nullptr;
+    };
+    std::vector<std::thread> threads;
+    threads.reserve((size_t)B);
+    for (int k = 0; k < B; ++k) threads.emplace_back(worker, k);
+    for (auto& t : threads) t.join();
+  };
+  std::vector<int> all((size_t)n_units);
+  for (int u = 0; u < n_units; ++u) all[(size_t)u] = u;
+  bool all_lenient = true;
+  for (int k = 0; k < B; ++k) all_lenient = all_lenient && saved_strict[(size_t)k] == 0;
+  if (!all_lenient) {  // the caller wants the error (strict contexts): one phase, nothing to defer
+    run_units(all, false);
+    return NK_OK;
+  }
+  const bool cv_trace = getenv("NYSKOOP_CV_TRACE") != nullptr;
+  const auto t_start = std::chrono::steady_clock::now();
+  for (int k = 0; k < B; ++k) members[k]->strict_spd = 1;
+  run_units(all, true);
+  for (int k = 0; k < B; ++k) members[k]->strict_spd = saved_strict[(size_t)k];
+  const auto t_mid = std::chrono::steady_clock::now();
+  if (!deferred.empty()) {
+    std::sort(deferred.begin(), deferred.end());
+    for (int k = 0; k < B; ++k) members[k]->strict_spd = 0;
+    run_units(deferred, false);
+    for (int k = 0; k < B; ++k) members[k]->strict_spd = saved_strict[(size_t)k];
+  }
+  if (cv_trace)
+    fprintf(stderr, "[nyskoop] cv_grid: %d units in %.3f s, %zu rank-deficient units again in %.3f s (%d members)\n", n_units,
+            std::chrono::duration<double>(t_mid - t_start).count(), deferred.size(),
+            std::chrono::duration<double>(std::chrono::steady_clock::now() - t_mid).count(), B);
   return NK_OK;
 }
 
