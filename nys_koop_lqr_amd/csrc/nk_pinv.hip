@@ -20,8 +20,10 @@
 // -- plus the isolated-cluster rule documented at pinv_scale_kernel for matrices with an exact null space, whose
 // rounding-level singular values a general symmetric matrix leaves at (1..50) eps sigma_max even under Jacobi.
 //
-// This is the rare path: a 500 x 500 system takes ~20 sweeps = 10^4 small launches (tens of milliseconds), a 2000 x 2000
-// one about a second; it is never entered when the Cholesky succeeds with pivots above the rounding level.
+// This is the rare path: a 500 x 500 system of the cloth grid takes 20-35 sweeps (the iteration works on P itself, i.e. on
+// the squared spectrum of a factor, and converges linearly for most of them) of 505 rounds, each of which reads and
+// writes all of W and V (4 MB): 0.14 s alone -- bound by that traffic, not by the launches; a 2000 x 2000 one takes seconds.
+// It is never entered when the Cholesky succeeds with pivots above the rounding level.
 #include "nk_common.h"
 
 #include <cmath>
@@ -47,6 +49,7 @@ __device__ __forceinline__ void rr_pair(int N, int r, int k, int* a, int* b) {
   }
 }
 
+constexpr int JAC_KPT = 8;  // entries of a row per thread held in registers (m <= 2048)
 __device__ __forceinline__ void jacobi_round_kernel_body(double* __restrict__ W, double* __restrict__ V, int m, int N, int round, double tol, const double* __restrict__ d_small2, int* __restrict__ rot_count) {
   __shared__ double sh[3][4];
   __shared__ double cs_sn[2];
@@ -56,12 +59,36 @@ __device__ __forceinline__ void jacobi_round_kernel_body(double* __restrict__ W,
   if (p > q) { const int t = p; p = q; q = t; }
   double* wp = W + (int64_t)p * m;
   double* wq = W + (int64_t)q * m;
+  double* vp = V + (int64_t)p * m;
+  double* vq = V + (int64_t)q * m;
+  // The launch is latency bound (one workgroup per pair, a few hundred workgroups): the four rows are fetched ONCE, all
+  // loads in flight together, and stay in registers for the rotation (m <= 2048; longer rows are read again below).
+  const bool in_regs = m <= 256 * JAC_KPT;
+  double x[JAC_KPT], y[JAC_KPT], vx[JAC_KPT], vy[JAC_KPT];
   double a = 0.0, b = 0.0, c = 0.0;
-  for (int k = threadIdx.x; k < m; k += 256) {
-    const double x = wp[k], y = wq[k];
-    a = fma(x, x, a);
-    b = fma(y, y, b);
-    c = fma(x, y, c);
+  if (in_regs) {
+#pragma unroll
+    for (int j = 0; j < JAC_KPT; ++j) {
+      const int k = threadIdx.x + 256 * j;
+      const bool ok = k < m;
+      x[j] = ok ? wp[k] : 0.0;
+      y[j] = ok ? wq[k] : 0.0;
+      vx[j] = ok ? vp[k] : 0.0;
+      vy[j] = ok ? vq[k] : 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < JAC_KPT; ++j) {  // same order of accumulation as the strided loop below
+      a = fma(x[j], x[j], a);
+      b = fma(y[j], y[j], b);
+      c = fma(x[j], y[j], c);
+    }
+  } else {
+    for (int k = threadIdx.x; k < m; k += 256) {
+      const double xx = wp[k], yy = wq[k];
+      a = fma(xx, xx, a);
+      b = fma(yy, yy, b);
+      c = fma(xx, yy, c);
+    }
   }
   a = wave_sum_p(a); b = wave_sum_p(b); c = wave_sum_p(c);
   const int w = threadIdx.x >> 6;
@@ -79,7 +106,8 @@ __device__ __forceinline__ void jacobi_round_kernel_body(double* __restrict__ W,
       const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
       cs = 1.0 / sqrt(1.0 + t * t);
       sn = cs * t;
-      atomicAdd(rot_count, 1);
+      rot_count[blockIdx.x] += 1;  // one slot per pair of the round: no contended atomic (250 same-address atomics from
+                                   // all XCDs cost ~25 us per launch, more than everything else in the round)
     }
     cs_sn[0] = cs;
     cs_sn[1] = sn;
@@ -87,19 +115,205 @@ __device__ __forceinline__ void jacobi_round_kernel_body(double* __restrict__ W,
   __syncthreads();
   const double cs = cs_sn[0], sn = cs_sn[1];
   if (sn == 0.0) return;
-  double* vp = V + (int64_t)p * m;
-  double* vq = V + (int64_t)q * m;
+  if (in_regs) {
+#pragma unroll
+    for (int j = 0; j < JAC_KPT; ++j) {
+      const int k = threadIdx.x + 256 * j;
+      if (k < m) {
+        wp[k] = cs * x[j] - sn * y[j];
+        wq[k] = sn * x[j] + cs * y[j];
+        vp[k] = cs * vx[j] - sn * vy[j];
+        vq[k] = sn * vx[j] + cs * vy[j];
+      }
+    }
+    return;
+  }
   for (int k = threadIdx.x; k < m; k += 256) {
-    const double x = wp[k], y = wq[k];
-    wp[k] = cs * x - sn * y;
-    wq[k] = sn * x + cs * y;
-    const double vx = vp[k], vy = vq[k];
-    vp[k] = cs * vx - sn * vy;
-    vq[k] = sn * vx + cs * vy;
+    const double xx = wp[k], yy = wq[k];
+    wp[k] = cs * xx - sn * yy;
+    wq[k] = sn * xx + cs * yy;
+    const double vxx = vp[k], vyy = vq[k];
+    vp[k] = cs * vxx - sn * vyy;
+    vq[k] = sn * vxx + cs * vyy;
   }
 }
 __global__ void __launch_bounds__(256) jacobi_round_kernel(double* __restrict__ W, double* __restrict__ V, int m, int N, int round, double tol, const double* __restrict__ d_small2, int* __restrict__ rot_count) { jacobi_round_kernel_body(W, V, m, N, round, tol, d_small2, rot_count); }
 NK_BATCHED_TWIN(jacobi_round_kernel, (256), double*, double*, int, int, int, double, const double*, int*)
+
+// m <= 512: one WAVE per pair (four pairs per workgroup), the rows in registers, no LDS and no workgroup barrier.  With a
+// workgroup per pair a launch over several lock-step units (9 x 253 workgroups of 256 threads) did not fit the chip at once
+// and ran as 2-3 rounds of latency-bound workgroups (26-33 us per launch, profiles of the cloth grid); as waves all pairs
+// are resident together.
+__device__ __forceinline__ double wave_allsum_p(double v) {
+  v = wave_sum_p(v);
+  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+__device__ __forceinline__ void jacobi_round_wave_kernel_body(double* __restrict__ W, double* __restrict__ V, int m, int N, int round, double tol, const double* __restrict__ d_small2, int* __restrict__ rot_count) {
+  const int lane = threadIdx.x & 63;
+  const int pair = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (pair >= N / 2) return;
+  int p, q;
+  rr_pair(N, round, pair, &p, &q);
+  if (p >= m || q >= m) return;  // the dummy player of an odd m
+  if (p > q) { const int t = p; p = q; q = t; }
+  double* wp = W + (int64_t)p * m;
+  double* wq = W + (int64_t)q * m;
+  double* vp = V + (int64_t)p * m;
+  double* vq = V + (int64_t)q * m;
+  double x[JAC_KPT], y[JAC_KPT], vx[JAC_KPT], vy[JAC_KPT];
+#pragma unroll
+  for (int j = 0; j < JAC_KPT; ++j) {
+    const int k = lane + 64 * j;
+    const bool ok = k < m;
+    x[j] = ok ? wp[k] : 0.0;
+    y[j] = ok ? wq[k] : 0.0;
+    vx[j] = ok ? vp[k] : 0.0;
+    vy[j] = ok ? vq[k] : 0.0;
+  }
+  double a = 0.0, b = 0.0, c = 0.0;
+#pragma unroll
+  for (int j = 0; j < JAC_KPT; ++j) {
+    a = fma(x[j], x[j], a);
+    b = fma(y[j], y[j], b);
+    c = fma(x[j], y[j], c);
+  }
+  a = wave_allsum_p(a); b = wave_allsum_p(b); c = wave_allsum_p(c);
+  const double small2 = d_small2[0];
+  const bool dead = a < small2 || b < small2;  // a column below the cut-off takes no further part
+  if (dead || c == 0.0 || !(fabs(c) > tol * sqrt(a) * sqrt(b))) return;  // wave-uniform
+  const double zeta = (b - a) / (2.0 * c);
+  const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+  const double cs = 1.0 / sqrt(1.0 + t * t);
+  const double sn = cs * t;
+  if (lane == 0) rot_count[pair] += 1;  // one slot per pair of the round (see jacobi_round_kernel)
+  if (sn == 0.0) return;
+#pragma unroll
+  for (int j = 0; j < JAC_KPT; ++j) {
+    const int k = lane + 64 * j;
+    if (k < m) {
+      wp[k] = cs * x[j] - sn * y[j];
+      wq[k] = sn * x[j] + cs * y[j];
+      vp[k] = cs * vx[j] - sn * vy[j];
+      vq[k] = sn * vx[j] + cs * vy[j];
+    }
+  }
+}
+__global__ void __launch_bounds__(256) jacobi_round_wave_kernel(double* __restrict__ W, double* __restrict__ V, int m, int N, int round, double tol, const double* __restrict__ d_small2, int* __restrict__ rot_count) { jacobi_round_wave_kernel_body(W, V, m, N, round, tol, d_small2, rot_count); }
+NK_BATCHED_TWIN(jacobi_round_wave_kernel, (256), double*, double*, int, int, int, double, const double*, int*)
+
+// A whole SWEEP (N - 1 rounds) in one launch for m <= 512: 16 pairs per 1024-thread workgroup, at most 16 workgroups, a
+// software barrier between rounds (one agent-scope atomic per workgroup and round; every workgroup is resident: 16
+// workgroups of this size fit 16 CUs, and a merged lock-step launch of 32 units 512 slots of the chip's 512).  A kernel
+// boundary per round costs ~25 us here -- not the launch itself but the L2 write-back / invalidate of the 4 MB of W and V
+// that every round rewrites (profiles of the cloth grid: 27 us per round launch whatever the kernel does) -- so the rows
+// are read and written with agent-scope accesses instead, which stay coherent across XCDs without flushing anything.
+// sync[0] = arrival counter (zeroed by the host before the launch), sync[1] = raised when a wait gives up (the host then
+// continues with one launch per round; the matrices are left in a consistent state: a rotation is either fully applied
+// or not at all, because a wave only gives up between rounds).
+constexpr int JAC_SPIN_LIMIT = 1 << 20;
+__device__ __forceinline__ double ld_agent(const double* p) {
+  return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED,
+                                                           __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void st_agent(double* p, double v) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void jacobi_sweep_kernel_body(double* __restrict__ W, double* __restrict__ V, int m, int N, double tol, const double* __restrict__ d_small2, int* __restrict__ rot_slots, int* __restrict__ sync) {
+  __shared__ int give_up;
+  const int lane = threadIdx.x & 63;
+  const int pair = blockIdx.x * 16 + (threadIdx.x >> 6);
+  const int nwg = gridDim.x;
+  const double small2 = d_small2[0];
+  int rotations = 0;
+  if (threadIdx.x == 0) give_up = 0;
+  __syncthreads();
+  for (int round = 0; round < N - 1; ++round) {
+    int p = m, q = m;
+    if (pair < N / 2) rr_pair(N, round, pair, &p, &q);
+    if (p < m && q < m) {  // wave-uniform (the dummy player of an odd m, the padding waves of the last workgroup)
+      if (p > q) { const int t = p; p = q; q = t; }
+      double* wp = W + (int64_t)p * m;
+      double* wq = W + (int64_t)q * m;
+      double* vp = V + (int64_t)p * m;
+      double* vq = V + (int64_t)q * m;
+      double x[JAC_KPT], y[JAC_KPT], vx[JAC_KPT], vy[JAC_KPT];
+#pragma unroll
+      for (int j = 0; j < JAC_KPT; ++j) {
+        const int k = lane + 64 * j;
+        const bool ok = k < m;
+        x[j] = ok ? ld_agent(wp + k) : 0.0;
+        y[j] = ok ? ld_agent(wq + k) : 0.0;
+        vx[j] = ok ? ld_agent(vp + k) : 0.0;
+        vy[j] = ok ? ld_agent(vq + k) : 0.0;
+      }
+      double a = 0.0, b = 0.0, c = 0.0;
+#pragma unroll
+      for (int j = 0; j < JAC_KPT; ++j) {
+        a = fma(x[j], x[j], a);
+        b = fma(y[j], y[j], b);
+        c = fma(x[j], y[j], c);
+      }
+      a = wave_allsum_p(a); b = wave_allsum_p(b); c = wave_allsum_p(c);
+      const bool dead = a < small2 || b < small2;
+      if (!dead && c != 0.0 && fabs(c) > tol * sqrt(a) * sqrt(b)) {
+        const double zeta = (b - a) / (2.0 * c);
+        const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+        const double cs = 1.0 / sqrt(1.0 + t * t);
+        const double sn = cs * t;
+        ++rotations;
+        if (sn != 0.0) {
+#pragma unroll
+          for (int j = 0; j < JAC_KPT; ++j) {
+            const int k = lane + 64 * j;
+            if (k < m) {
+              st_agent(wp + k, cs * x[j] - sn * y[j]);
+              st_agent(wq + k, sn * x[j] + cs * y[j]);
+              st_agent(vp + k, cs * vx[j] - sn * vy[j]);
+              st_agent(vq + k, sn * vx[j] + cs * vy[j]);
+            }
+          }
+        }
+      }
+    }
+    if (round + 1 == N - 1) break;  // nobody reads after the last round: the kernel boundary publishes it
+    // ---- barrier over the launch's workgroups (of this unit): the stores above have been acknowledged (vmcnt(0) in
+    //      __syncthreads) before thread 0 announces the workgroup
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __hip_atomic_fetch_add(sync, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      const int target = nwg * (round + 1);
+      int polls = 0;
+      while (__hip_atomic_load(sync, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        if (__hip_atomic_load(sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 || ++polls >= JAC_SPIN_LIMIT) {
+          __hip_atomic_store(sync + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          give_up = 1;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(2);
+      }
+    }
+    __syncthreads();
+    if (give_up) break;
+  }
+  if (lane == 0 && pair < N / 2) rot_slots[pair] += rotations;
+}
+__global__ void __launch_bounds__(1024) jacobi_sweep_kernel(double* __restrict__ W, double* __restrict__ V, int m, int N, double tol, const double* __restrict__ d_small2, int* __restrict__ rot_slots, int* __restrict__ sync) { jacobi_sweep_kernel_body(W, V, m, N, tol, d_small2, rot_slots, sync); }
+NK_BATCHED_TWIN(jacobi_sweep_kernel, (1024), double*, double*, int, int, double, const double*, int*, int*)
+
+// total[0] = sum of the per-pair rotation counters of a sweep; the counters are cleared for the next sweep.  One workgroup.
+__device__ __forceinline__ void rot_total_kernel_body(int* __restrict__ slots, int n, int* __restrict__ total) {
+  __shared__ int part[4];
+  int s = 0;
+  for (int j = threadIdx.x; j < n; j += 256) { s += slots[j]; slots[j] = 0; }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) total[0] = part[0] + part[1] + part[2] + part[3];
+}
+__global__ void __launch_bounds__(256) rot_total_kernel(int* __restrict__ slots, int n, int* __restrict__ total) { rot_total_kernel_body(slots, n, total); }
+NK_BATCHED_TWIN(rot_total_kernel, (256), int*, int, int*)
 
 // sig2[j] = |row j of W|^2, one wave per row
 __device__ __forceinline__ void row_sumsq_kernel_body(const double* __restrict__ W, int m, double* __restrict__ sig2) {
@@ -242,7 +456,9 @@ int pinv_right_divide(nk_ctx* ctx, const double* P, int64_t ldp, int m, const do
   NK_TRY(arena_alloc_t(ctx, (size_t)m, &scale));
   NK_TRY(arena_alloc_t(ctx, (size_t)(rows > 0 ? rows : 1) * m, &T));
   NK_TRY(arena_alloc_t(ctx, (size_t)8, &d_out));
-  NK_TRY(arena_alloc_t(ctx, (size_t)2, &d_rot));
+  // d_rot[0] = rotations of the last sweep, d_rot[2 ...] = one counter per pair of a round (ints)
+  NK_TRY(arena_alloc_t(ctx, (size_t)m + 8, &d_rot));
+  NK_HIP(hipMemsetAsync(d_rot, 0, ((size_t)m + 8) * sizeof(int), ctx->stream));
   NK_TRY(launch_copy2d(ctx, P, ldp, W, m, m, m));
   NK_TRY(launch_fill(ctx, V, m, m, m, 0.0));
   NK_TRY(launch_add_diag(ctx, V, m, m, 1.0));
@@ -265,19 +481,46 @@ int pinv_right_divide(nk_ctx* ctx, const double* P, int64_t ldp, int m, const do
   // less than 1e-3 eps sigma_max); NYSKOOP_PINV_DEAD overrides the factor for experiments
   const double dead_rel = getenv("NYSKOOP_PINV_DEAD") ? atof(getenv("NYSKOOP_PINV_DEAD")) : 1e-3 * rcond;
   int sweeps = 0, last_rot = -1;
+  // A sweep as ONE launch pays inside a lock-step group (several units per launch: 72 MB move per round, the launch is
+  // bandwidth bound and the kernel boundaries of 505 launches per sweep add their L2 write-backs: 1.10 -> 0.74 s for the 16
+  // rank-deficient units of the cloth grid); a single solve is faster with a launch per round (5 us per round against
+  // 8.5 us with the software barrier: 140 against 235 ms at m = 506, tools/jacobi_bench.py).  NYSKOOP_PINV_SWEEP_LAUNCH=0/1
+  // forces either.
+  const char* sweep_env = getenv("NYSKOOP_PINV_SWEEP_LAUNCH");
+  bool one_launch = sweep_env ? sweep_env[0] != '0' : ctx_recording(ctx);
+  int* d_sync = d_rot + 2 + (N / 2 + 2);
   if (m > 1) {
     for (; sweeps < max_sweeps; ++sweeps) {
-      NK_HIP(hipMemsetAsync(d_rot, 0, sizeof(int), ctx->stream));
       // refresh the dead-column threshold from the current column norms
       hipLaunchKernelGGL(row_sumsq_kernel, dim3((m + 3) / 4), dim3(256), 0, ctx->stream, W, m, sig2);
       hipLaunchKernelGGL(dead_threshold_kernel, dim3(1), dim3(256), 0, ctx->stream, sig2, m, dead_rel, d_out + 4);
-      for (int r = 0; r < N - 1; ++r)
-        hipLaunchKernelGGL(jacobi_round_kernel, dim3(N / 2), dim3(256), 0, ctx->stream, W, V, m, N, r, tol, d_out + 4, d_rot);
+      if (m <= 64 * JAC_KPT && one_launch) {
+        NK_HIP(hipMemsetAsync(d_sync, 0, 2 * sizeof(int), ctx->stream));
+        hipLaunchKernelGGL(jacobi_sweep_kernel, dim3((N / 2 + 15) / 16), dim3(1024), 0, ctx->stream, W, V, m, N, tol, d_out + 4,
+                           d_rot + 2, d_sync);
+        NK_HIP(hipMemcpyAsync(ctx->h_info + 9, d_sync + 1, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+      } else if (m <= 64 * JAC_KPT) {
+        for (int r = 0; r < N - 1; ++r)
+          hipLaunchKernelGGL(jacobi_round_wave_kernel, dim3((N / 2 + 3) / 4), dim3(256), 0, ctx->stream, W, V, m, N, r, tol,
+                             d_out + 4, d_rot + 2);
+      } else {
+        for (int r = 0; r < N - 1; ++r)
+          hipLaunchKernelGGL(jacobi_round_kernel, dim3(N / 2), dim3(256), 0, ctx->stream, W, V, m, N, r, tol, d_out + 4,
+                             d_rot + 2);
+      }
+      hipLaunchKernelGGL(rot_total_kernel, dim3(1), dim3(256), 0, ctx->stream, d_rot + 2, N / 2, d_rot);
       NK_HIP(hipGetLastError());
       NK_HIP(hipMemcpyAsync(ctx->h_info + 8, d_rot, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
       NK_HIP(hipStreamSynchronize(ctx->stream));
       last_rot = ctx->h_info[8];
       if (trace) fprintf(stderr, "[nk pinv] m=%d sweep %d: %d rotations\n", m, sweeps, last_rot);
+      if (one_launch && m <= 64 * JAC_KPT && ctx->h_info[9] != 0) {
+        // a workgroup gave up waiting for the others (they were not all resident): finish with one launch per round
+        ctx->h_info[9] = 0;
+        one_launch = false;
+        if (trace) fprintf(stderr, "[nk pinv] single-launch sweep gave up waiting: one launch per round from here\n");
+        continue;
+      }
       if (last_rot == 0) { ++sweeps; break; }
     }
   }
