@@ -347,3 +347,46 @@ int launch_kmat_gram(nk_ctx* ctx, int ktype, const double* At, int64_t ldat, con
                      const double* Bt, int64_t ldbt, const double* sqb, int64_t nB, int d, double sigma0, double* out,
                      int64_t ldo);
 }  // namespace nk
+
+// ---- cross-lane helpers for fp64 on gfx950 (no LDS traffic): DPP moves inside a 16-lane row, v_permlane16_swap /
+//      v_permlane32_swap between rows and half waves (checked lane by lane on the device by tools/reduce_probe.hip)
+#if defined(__HIPCC__)
+namespace nk {
+typedef unsigned chain_u2 __attribute__((ext_vector_type(2)));
+template <int CTRL> __device__ __forceinline__ double dpp_f64(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+// rows 1 and 3 (lanes 16-31, 48-63) of a change places with rows 0 and 2 of b
+__device__ __forceinline__ void swap16_f64(double& a, double& b) {
+  const chain_u2 lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+  const chain_u2 hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+  a = __hiloint2double((int)hi.x, (int)lo.x);
+  b = __hiloint2double((int)hi.y, (int)lo.y);
+}
+// lanes 32-63 of a change places with lanes 0-31 of b
+__device__ __forceinline__ void swap32_f64(double& a, double& b) {
+  const chain_u2 lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+  const chain_u2 hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+  a = __hiloint2double((int)hi.x, (int)lo.x);
+  b = __hiloint2double((int)hi.y, (int)lo.y);
+}
+// sum of one value over the 64 lanes, in every lane, without the LDS crossbar (a __shfl_down reduction is six dependent
+// ds_bpermute round trips)
+__device__ __forceinline__ double wave_sum64_dpp(double c) {
+  c += dpp_f64<0xB1>(c);   // quad_perm [1,0,3,2]
+  c += dpp_f64<0x4E>(c);   // quad_perm [2,3,0,1]
+  c += dpp_f64<0x141>(c);  // row_half_mirror
+  c += dpp_f64<0x140>(c);  // row_mirror: every lane of a 16-lane row holds the row total
+  double a = c, b = c;
+  swap16_f64(a, b);
+  c = a + b;               // rows 0+1, 2+3
+  a = c; b = c;
+  swap32_f64(a, b);
+  return a + b;
+}
+
+}  // namespace nk
+#endif

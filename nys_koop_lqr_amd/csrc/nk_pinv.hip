@@ -144,10 +144,7 @@ NK_BATCHED_TWIN(jacobi_round_kernel, (256), double*, double*, int, int, int, dou
 // workgroup per pair a launch over several lock-step units (9 x 253 workgroups of 256 threads) did not fit the chip at once
 // and ran as 2-3 rounds of latency-bound workgroups (26-33 us per launch, profiles of the cloth grid); as waves all pairs
 // are resident together.
-__device__ __forceinline__ double wave_allsum_p(double v) {
-  v = wave_sum_p(v);
-  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
-}
+__device__ __forceinline__ double wave_allsum_p(double v) { return wave_sum64_dpp(v); }  // every lane gets the total
 __device__ __forceinline__ void jacobi_round_wave_kernel_body(double* __restrict__ W, double* __restrict__ V, int m, int N, int round, double tol, const double* __restrict__ d_small2, int* __restrict__ rot_count) {
   const int lane = threadIdx.x & 63;
   const int pair = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -300,6 +297,126 @@ __device__ __forceinline__ void jacobi_sweep_kernel_body(double* __restrict__ W,
 }
 __global__ void __launch_bounds__(1024) jacobi_sweep_kernel(double* __restrict__ W, double* __restrict__ V, int m, int N, double tol, const double* __restrict__ d_small2, int* __restrict__ rot_slots, int* __restrict__ sync) { jacobi_sweep_kernel_body(W, V, m, N, tol, d_small2, rot_slots, sync); }
 NK_BATCHED_TWIN(jacobi_sweep_kernel, (1024), double*, double*, int, int, double, const double*, int*, int*)
+
+// ---------------------------------------------------------------------------------------------------------------
+// Block Jacobi (m <= 2048): the scalar rounds above move ALL of W and V through memory once per round, 505 times per
+// sweep at m = 506 -- the fallback is bound by that traffic (4 GB per sweep and unit), not by launches or arithmetic.
+// Here the rows are grouped in blocks of B; a workgroup takes a PAIR of blocks (2B rows of W and of V, 128 KB) into LDS
+// and runs a full round-robin sweep over the 2B rows there (2B - 1 inner rounds, one wave per pair, the four rows of a
+// pair in registers between the dot products and the rotation), then writes the rows back.  An outer sweep is a
+// round-robin over the blocks: NB - 1 launches of NB / 2 workgroups, each of which moves W and V once -- 8 x fewer bytes
+// and launches per sweep at B = 8.  Every pair of rows meets at least once per outer sweep (pairs inside a block meet in
+// every round their block takes part in, where they are already orthogonal and are skipped), so "no rotation in a whole
+// outer sweep" is the same convergence criterion as before.  B x row length <= 4096 doubles: B = 8 for m <= 512, 4 for
+// m <= 1024, 2 for m <= 2048.
+// ---------------------------------------------------------------------------------------------------------------
+template <int B, int KPT>
+__device__ __forceinline__ void jacobi_block_body(double* __restrict__ W, double* __restrict__ V, int m, int NB, int round, double tol, const double* __restrict__ d_small2, int* __restrict__ rot_slots) {
+  extern __shared__ __attribute__((aligned(16))) double jb_lds[];
+  constexpr int LDW = 64 * KPT;
+  double* Ws = jb_lds;
+  double* Vs = jb_lds + 2 * B * LDW;
+  __shared__ int rot_wg;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int bi, bj;
+  rr_pair(NB, round, blockIdx.x, &bi, &bj);
+  if (bi > bj) { const int t = bi; bi = bj; bj = t; }
+  if (bi * B >= m) return;  // both blocks are padding
+  if (threadIdx.x == 0) rot_wg = 0;
+  // global row of local row r
+  auto grow = [&](int r) { return r < B ? bi * B + r : bj * B + (r - B); };
+  for (int r = wave; r < 2 * B; r += B) {
+    const int gi = grow(r);
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) {
+      const int k = lane + 64 * j;
+      const bool ok = gi < m && k < m;
+      Ws[r * LDW + k] = ok ? W[(int64_t)gi * m + k] : 0.0;
+      Vs[r * LDW + k] = ok ? V[(int64_t)gi * m + k] : 0.0;
+    }
+  }
+  __syncthreads();
+  const double small2 = d_small2[0];
+  int rotations = 0;
+  for (int ir = 0; ir < 2 * B - 1; ++ir) {
+    int p, q;
+    rr_pair(2 * B, ir, wave, &p, &q);
+    if (p > q) { const int t = p; p = q; q = t; }
+    if (grow(p) < m && grow(q) < m) {  // wave-uniform
+      double* wp = Ws + p * LDW;
+      double* wq = Ws + q * LDW;
+      double x[KPT], y[KPT];
+      double a = 0.0, b = 0.0, c = 0.0;
+#pragma unroll
+      for (int j = 0; j < KPT; ++j) {
+        x[j] = wp[lane + 64 * j];
+        y[j] = wq[lane + 64 * j];
+        a = fma(x[j], x[j], a);
+        b = fma(y[j], y[j], b);
+        c = fma(x[j], y[j], c);
+      }
+      a = wave_allsum_p(a); b = wave_allsum_p(b); c = wave_allsum_p(c);
+      const bool dead = a < small2 || b < small2;
+      if (!dead && c != 0.0 && fabs(c) > tol * sqrt(a) * sqrt(b)) {
+        const double zeta = (b - a) / (2.0 * c);
+        const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+        const double cs = 1.0 / sqrt(1.0 + t * t);
+        const double sn = cs * t;
+        ++rotations;
+        if (sn != 0.0) {
+          double* vp = Vs + p * LDW;
+          double* vq = Vs + q * LDW;
+#pragma unroll
+          for (int j = 0; j < KPT; ++j) {
+            const int k = lane + 64 * j;
+            wp[k] = cs * x[j] - sn * y[j];
+            wq[k] = sn * x[j] + cs * y[j];
+            const double vx = vp[k], vy = vq[k];
+            vp[k] = cs * vx - sn * vy;
+            vq[k] = sn * vx + cs * vy;
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  for (int r = wave; r < 2 * B; r += B) {
+    const int gi = grow(r);
+    if (gi < m) {
+#pragma unroll
+      for (int j = 0; j < KPT; ++j) {
+        const int k = lane + 64 * j;
+        if (k < m) {
+          W[(int64_t)gi * m + k] = Ws[r * LDW + k];
+          V[(int64_t)gi * m + k] = Vs[r * LDW + k];
+        }
+      }
+    }
+  }
+  if (lane == 0 && rotations != 0) atomicAdd(&rot_wg, rotations);
+  __syncthreads();
+  if (threadIdx.x == 0) rot_slots[blockIdx.x] += rot_wg;
+}
+constexpr int JB_LDS_BYTES = 2 * 2 * 4096 * 8;  // W and V rows of a block pair: 2 x 2B x (64 KPT) doubles with B KPT = 64
+__device__ __forceinline__ void jacobi_block8_kernel_body(double* __restrict__ W, double* __restrict__ V, int m, int NB, int round, double tol, const double* __restrict__ d_small2, int* __restrict__ rot_slots) { jacobi_block_body<8, 8>(W, V, m, NB, round, tol, d_small2, rot_slots); }
+__device__ __forceinline__ void jacobi_block4_kernel_body(double* __restrict__ W, double* __restrict__ V, int m, int NB, int round, double tol, const double* __restrict__ d_small2, int* __restrict__ rot_slots) { jacobi_block_body<4, 16>(W, V, m, NB, round, tol, d_small2, rot_slots); }
+__device__ __forceinline__ void jacobi_block2_kernel_body(double* __restrict__ W, double* __restrict__ V, int m, int NB, int round, double tol, const double* __restrict__ d_small2, int* __restrict__ rot_slots) { jacobi_block_body<2, 32>(W, V, m, NB, round, tol, d_small2, rot_slots); }
+__global__ void __launch_bounds__(512) jacobi_block8_kernel(double* __restrict__ W, double* __restrict__ V, int m, int NB, int round, double tol, const double* __restrict__ d_small2, int* __restrict__ rot_slots) { jacobi_block8_kernel_body(W, V, m, NB, round, tol, d_small2, rot_slots); }
+__global__ void __launch_bounds__(256) jacobi_block4_kernel(double* __restrict__ W, double* __restrict__ V, int m, int NB, int round, double tol, const double* __restrict__ d_small2, int* __restrict__ rot_slots) { jacobi_block4_kernel_body(W, V, m, NB, round, tol, d_small2, rot_slots); }
+__global__ void __launch_bounds__(128) jacobi_block2_kernel(double* __restrict__ W, double* __restrict__ V, int m, int NB, int round, double tol, const double* __restrict__ d_small2, int* __restrict__ rot_slots) { jacobi_block2_kernel_body(W, V, m, NB, round, tol, d_small2, rot_slots); }
+NK_BATCHED_TWIN(jacobi_block8_kernel, (512), double*, double*, int, int, int, double, const double*, int*)
+NK_BATCHED_TWIN(jacobi_block4_kernel, (256), double*, double*, int, int, int, double, const double*, int*)
+NK_BATCHED_TWIN(jacobi_block2_kernel, (128), double*, double*, int, int, int, double, const double*, int*)
+static bool g_jb_attr_set = false;
+static int jacobi_block_attrs() {
+  if (g_jb_attr_set) return NK_OK;
+  const void* fns[6] = {reinterpret_cast<const void*>(jacobi_block8_kernel), reinterpret_cast<const void*>(jacobi_block4_kernel),
+                        reinterpret_cast<const void*>(jacobi_block2_kernel), reinterpret_cast<const void*>(jacobi_block8_kernel_batched),
+                        reinterpret_cast<const void*>(jacobi_block4_kernel_batched), reinterpret_cast<const void*>(jacobi_block2_kernel_batched)};
+  for (const void* f : fns) NK_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, JB_LDS_BYTES));
+  g_jb_attr_set = true;
+  return NK_OK;
+}
 
 // total[0] = sum of the per-pair rotation counters of a sweep; the counters are cleared for the next sweep.  One workgroup.
 __device__ __forceinline__ void rot_total_kernel_body(int* __restrict__ slots, int n, int* __restrict__ total) {
@@ -489,12 +606,31 @@ int pinv_right_divide(nk_ctx* ctx, const double* P, int64_t ldp, int m, const do
   const char* sweep_env = getenv("NYSKOOP_PINV_SWEEP_LAUNCH");
   bool one_launch = sweep_env ? sweep_env[0] != '0' : ctx_recording(ctx);
   int* d_sync = d_rot + 2 + (N / 2 + 2);
+  // block Jacobi (default for m <= 2048; NYSKOOP_PINV_BLOCK=0 selects the scalar rounds)
+  int block_b = 0;
+  if (!(getenv("NYSKOOP_PINV_BLOCK") && getenv("NYSKOOP_PINV_BLOCK")[0] == '0') && m >= 4)
+    block_b = m <= 512 ? 8 : (m <= 1024 ? 4 : (m <= 2048 ? 2 : 0));
+  int NB = 0;
+  if (block_b > 0) {
+    NB = (m + block_b - 1) / block_b;
+    NB += NB & 1;
+    NK_TRY(jacobi_block_attrs());
+  }
   if (m > 1) {
     for (; sweeps < max_sweeps; ++sweeps) {
       // refresh the dead-column threshold from the current column norms
       hipLaunchKernelGGL(row_sumsq_kernel, dim3((m + 3) / 4), dim3(256), 0, ctx->stream, W, m, sig2);
       hipLaunchKernelGGL(dead_threshold_kernel, dim3(1), dim3(256), 0, ctx->stream, sig2, m, dead_rel, d_out + 4);
-      if (m <= 64 * JAC_KPT && one_launch) {
+      if (block_b > 0) {
+        for (int r = 0; r < NB - 1; ++r) {
+          if (block_b == 8)
+            hipLaunchKernelGGL(jacobi_block8_kernel, dim3(NB / 2), dim3(512), JB_LDS_BYTES, ctx->stream, W, V, m, NB, r, tol, d_out + 4, d_rot + 2);
+          else if (block_b == 4)
+            hipLaunchKernelGGL(jacobi_block4_kernel, dim3(NB / 2), dim3(256), JB_LDS_BYTES, ctx->stream, W, V, m, NB, r, tol, d_out + 4, d_rot + 2);
+          else
+            hipLaunchKernelGGL(jacobi_block2_kernel, dim3(NB / 2), dim3(128), JB_LDS_BYTES, ctx->stream, W, V, m, NB, r, tol, d_out + 4, d_rot + 2);
+        }
+      } else if (m <= 64 * JAC_KPT && one_launch) {
         NK_HIP(hipMemsetAsync(d_sync, 0, 2 * sizeof(int), ctx->stream));
         hipLaunchKernelGGL(jacobi_sweep_kernel, dim3((N / 2 + 15) / 16), dim3(1024), 0, ctx->stream, W, V, m, N, tol, d_out + 4,
                            d_rot + 2, d_sync);
@@ -508,13 +644,13 @@ int pinv_right_divide(nk_ctx* ctx, const double* P, int64_t ldp, int m, const do
           hipLaunchKernelGGL(jacobi_round_kernel, dim3(N / 2), dim3(256), 0, ctx->stream, W, V, m, N, r, tol, d_out + 4,
                              d_rot + 2);
       }
-      hipLaunchKernelGGL(rot_total_kernel, dim3(1), dim3(256), 0, ctx->stream, d_rot + 2, N / 2, d_rot);
+      hipLaunchKernelGGL(rot_total_kernel, dim3(1), dim3(256), 0, ctx->stream, d_rot + 2, block_b > 0 ? NB / 2 : N / 2, d_rot);
       NK_HIP(hipGetLastError());
       NK_HIP(hipMemcpyAsync(ctx->h_info + 8, d_rot, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
       NK_HIP(hipStreamSynchronize(ctx->stream));
       last_rot = ctx->h_info[8];
       if (trace) fprintf(stderr, "[nk pinv] m=%d sweep %d: %d rotations\n", m, sweeps, last_rot);
-      if (one_launch && m <= 64 * JAC_KPT && ctx->h_info[9] != 0) {
+      if (block_b == 0 && one_launch && m <= 64 * JAC_KPT && ctx->h_info[9] != 0) {
         // a workgroup gave up waiting for the others (they were not all resident): finish with one launch per round
         ctx->h_info[9] = 0;
         one_launch = false;
