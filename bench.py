@@ -153,13 +153,21 @@ def cv_sweep_rate(nk, workers=4):
     t0 = time.perf_counter()
     harness.grid_search_cv(X, Y, p, cands[:9], centers=centers)
     dt1 = time.perf_counter() - t0
-    harness.grid_search_cv(X, Y, p, cands, centers=centers, batch=30, batch_groups=3)  # warm-up of every group member
-    dt = 1e9
-    for _ in range(3):
-        t0 = time.perf_counter()
-        res = harness.grid_search_cv(X, Y, p, cands, centers=centers, batch=30, batch_groups=3)
-        dt = min(dt, time.perf_counter() - t0)
-    return dict(units_per_s=nu / dt, units=nu, seconds=dt, mode="lock-step batched: 3 groups x 30 units (nk_cv_grid)",
+    # two shapes of the lock-step pool (which one is ahead depends on the box: 2 x 32 is the steadier, 3 x 30 the faster one
+    # on some): the better of the two is reported, each the best of three sweeps after a warm-up of every group member
+    best = None
+    for batch, groups in ((32, 2), (30, 3)):
+        harness.grid_search_cv(X, Y, p, cands, centers=centers, batch=batch, batch_groups=groups)
+        dt = 1e9
+        for _ in range(3):
+            t0 = time.perf_counter()
+            res = harness.grid_search_cv(X, Y, p, cands, centers=centers, batch=batch, batch_groups=groups)
+            dt = min(dt, time.perf_counter() - t0)
+        if best is None or dt < best[0]:
+            best = (dt, batch, groups, res)
+    dt, batch, groups, res = best
+    return dict(units_per_s=nu / dt, units=nu, seconds=dt,
+                mode="lock-step batched: %d groups x %d units (nk_cv_grid)" % (groups, batch),
                 units_per_s_unbatched=45 / dt1, shape="n=1010 (808 train / 202 test) m=500 d=192 p=6",
                 bit_identical_to_unbatched=bool(np.array_equal(one["split_scores"], res["split_scores"][:9])),
                 finite=bool(np.all(np.isfinite(res["split_scores"]))))
