@@ -164,6 +164,19 @@ def check(rc):
         raise NyskoopError(rc, load_library().nk_last_error().decode("utf-8", "replace"))
 
 
+def torch_if_cuda():
+    """torch if it is importable and sees a HIP device (it is the allocator of device-resident intermediates where a
+    caller-side composition wants them, e.g. KoopmanKernelRegressor.fit), else None."""
+    try:
+        import torch
+    except Exception:  # noqa: BLE001 -- optional dependency
+        return None
+    try:
+        return torch if torch.cuda.is_available() else None
+    except Exception:  # noqa: BLE001
+        return None
+
+
 class Mat:
     """A row-major float64 matrix view handed to the C-ABI: host (numpy) or device (anything with
     data_ptr()/stride()/shape such as a torch.cuda tensor).  Keeps the owner alive for the call."""
@@ -172,7 +185,7 @@ class Mat:
         if hasattr(obj, "data_ptr") and hasattr(obj, "stride"):  # device tensor (duck-typed torch)
             if str(getattr(obj, "dtype", "")).split(".")[-1] not in ("float64", "double"):
                 raise TypeError("device tensors must be float64")
-            if obj.dim() != 2 or obj.stride(1) != 1:
+            if obj.dim() != 2 or (obj.shape[1] > 1 and obj.stride(1) != 1):  # (a size-1 dimension may carry any stride)
                 raise ValueError("device tensors must be 2-D with unit inner stride")
             self.owner, self.ptr, self.ld = obj, obj.data_ptr(), int(obj.stride(0))
             self.shape = (int(obj.shape[0]), int(obj.shape[1]))

@@ -28,20 +28,27 @@ class DeviceKernel:
         kd.lengthscale = ls.ctypes.data_as(C.POINTER(C.c_double))
         return kd, ls
 
-    def __call__(self, X, Y=None, device=None):
+    def __call__(self, X, Y=None, device=None, out=None):
+        """K(X, Y) as a NumPy array; with `out` (a float64 device tensor of shape (len(X), len(Y))) the result stays in
+        HBM and `out` is returned (X, Y may be device tensors as well)."""
         ctx = _lib.get_context(device)
         A = _lib.Mat(X)
         B = A if Y is None else _lib.Mat(Y)
         if A.shape[1] != B.shape[1]:
             raise ValueError(f"XA and XB must have the same number of columns ({A.shape[1]} != {B.shape[1]})")
         kd, keep = self.desc(A.shape[1])
-        out = np.empty((A.shape[0], B.shape[0]), dtype=np.float64)
-        rc = ctx.lib.nk_kernel_matrix(ctx.handle, C.byref(kd), A.ptr, A.ld, A.shape[0], B.ptr, B.ld, B.shape[0],
-                                      out.ctypes.data, max(out.shape[1], 1))
+        if out is None:
+            res = np.empty((A.shape[0], B.shape[0]), dtype=np.float64)
+            optr, old = res.ctypes.data, max(res.shape[1], 1)
+        else:
+            om = _lib.Mat(out, rows=A.shape[0], cols=B.shape[0])
+            res, optr, old = out, om.ptr, om.ld
+            ctx.wait_for(X, Y, out)
+        rc = ctx.lib.nk_kernel_matrix(ctx.handle, C.byref(kd), A.ptr, A.ld, A.shape[0], B.ptr, B.ld, B.shape[0], optr, old)
         if rc == -1:
             raise ValueError(ctx.lib.nk_last_error().decode())
         _lib.check(rc)
-        return out
+        return res
 
     def __repr__(self):
         name = {0: "RBF", 1: "Matern52", 2: "DotProduct"}[self.ktype]

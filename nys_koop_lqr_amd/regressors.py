@@ -6,6 +6,8 @@ kernels of libnyskoop.so through ctypes.  The DARE (control.dlqr in the referenc
 import ctypes as C
 import time
 
+import os
+
 import numpy as np
 from sklearn.base import BaseEstimator
 
@@ -538,6 +540,82 @@ class KoopmanKernelRegressor(KoopmanRegressor):
         _lib.check(rc)
         return X
 
+    # ---- device-resident composition: every N x N intermediate lives in HBM (torch tensors as the allocator), only the
+    #      attributes the reference exposes are copied to the host, once, at the end.  At config 2's N = 1e4 an N x N matrix
+    #      is 800 MB: the host-composed version below moves sixteen of them over PCIe.
+    @staticmethod
+    def _dgemm(ctx, A, B, out, tA=0, tB=0, beta=0.0):
+        a, b, o = _lib.Mat(A), _lib.Mat(B), _lib.Mat(out)
+        M, K = (a.shape[1], a.shape[0]) if tA else a.shape
+        N = b.shape[0] if tB else b.shape[1]
+        ctx.wait_for(A, B, out)
+        _lib.check(ctx.lib.nk_gemm(ctx.handle, int(tA), int(tB), M, N, K, 1.0, a.ptr, a.ld, b.ptr, b.ld, float(beta), o.ptr, o.ld))
+        return out
+
+    @staticmethod
+    def _dsolve(ctx, P, R, out):
+        pm, rm, om = _lib.Mat(P), _lib.Mat(R), _lib.Mat(out)
+        ctx.wait_for(P, R, out)
+        rc = ctx.lib.nk_solve_spd(ctx.handle, pm.ptr, pm.ld, pm.shape[0], rm.ptr, rm.ld, rm.shape[1], om.ptr, om.ld)
+        if rc == -3:
+            raise np.linalg.LinAlgError(ctx.lib.nk_last_error().decode())
+        _lib.check(rc)
+        return out
+
+    def _fit_device(self, ctx, torch, Xs, Us, Ys, N, gamma_n):
+        dev = torch.device("cuda", ctx.device)
+        f64 = torch.float64
+        up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        new = lambda r, c: torch.empty((r, c), dtype=f64, device=dev)
+        k = self.kernel.kernel
+        p = Us.shape[1]
+        Xs_d, Ys_d = up(Xs), up(Ys)
+        Us_d = up(Us) if p > 0 else None
+        K_ins = k(Xs_d, Xs_d, out=new(N, N))  # :82-84
+        if p > 0:
+            self._dgemm(ctx, Us_d, Us_d, K_ins, tB=1, beta=1.0)
+        K_ins.diagonal().add_(gamma_n)
+        Kout = k(Ys_d, Ys_d, out=new(N, N))  # :85
+        Kout.diagonal().add_(self.jitter)
+        S, Sinv = new(N, N), new(N, N)
+        it, res = C.c_int32(), C.c_double()
+        ctx.wait_for(Kout)
+        _lib.check(ctx.lib.nk_sqrtm_spd(ctx.handle, Kout.data_ptr(), N, N, S.data_ptr(), Sinv.data_ptr(), C.byref(it),
+                                        C.byref(res)))  # :87-88 (sqrtm, pinv)
+        Kxy = k(Xs_d, Ys_d, out=new(N, N))  # :90
+        right = new(N, N + p)  # :91-92: [(Sinv Kxy^T)^T | U]
+        self._dgemm(ctx, Kxy, Sinv, right[:, :N], tB=1)
+        if p > 0:
+            right[:, N:] = Us_d
+        del Kxy
+        sol = self._dsolve(ctx, K_ins, right, new(N, N + p))
+        del right, K_ins
+        G_ls = self._dgemm(ctx, S, sol, new(N, N + p))  # :93
+        del sol
+        Phi = self._dgemm(ctx, Kout, Sinv, new(N, N), tA=1, tB=1)  # :98 Phi = (Sinv Kout)^T
+        PPt = self._dgemm(ctx, Phi, Phi, new(N, N), tB=1)
+        PPt.diagonal().add_(gamma_n)
+        sol2 = self._dsolve(ctx, PPt, Phi, new(N, N))
+        del PPt, Phi
+        Yt_d = up(self.training_outputs)  # d x N
+        Cd = self._dgemm(ctx, Yt_d, sol2, new(Yt_d.shape[0], N))  # :99
+        del sol2
+        Wd = self._dgemm(ctx, Cd, G_ls, new(Cd.shape[0], N + p))  # :100-102
+        torch.cuda.synchronize(dev)
+        G_host = G_ls.cpu().numpy()
+        self.A = G_host[:, :N]
+        self.B = G_host[:, N:]
+        self.C = Cd.cpu().numpy()
+        self.weights = Wd.cpu().numpy()
+        self.Kout = Kout.cpu().numpy()
+        self.Kout_sqrt_inv = Sinv.cpu().numpy()
+        self._dev_cache = dict(Sinv=Sinv, Ys=Ys_d, device=ctx.device)  # lift() multiplies from HBM
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state.pop("_dev_cache", None)  # device tensors never travel
+        return state
+
     def fit(self, X, Y):
         ctx = _lib.get_context()
         X = np.asarray(X, dtype=np.float64).T  # (d+p) x N, as regressors.py:67-68
@@ -553,6 +631,10 @@ class KoopmanKernelRegressor(KoopmanRegressor):
         Xs = np.ascontiguousarray(self.training_inputs[:n_states, :].T)
         Us = np.ascontiguousarray(self.training_inputs[n_states:, :].T)  # N x p
         Ys = np.ascontiguousarray(self.training_outputs.T)
+        self.__dict__.pop("_dev_cache", None)
+        torch = _lib.torch_if_cuda()
+        if torch is not None and os.environ.get("NYSKOOP_EXACT_HOST", "0") != "1":
+            return self._fit_device(ctx, torch, Xs, Us, Ys, N, gamma_n)
         K_ins = k(Xs, Xs) + self._gemm(ctx, Us, Us.T) + gamma_n * np.eye(N)  # :82-84
         Kout = k(Ys, Ys) + self.jitter * np.eye(N)  # :85
         self.Kout = Kout
@@ -576,5 +658,14 @@ class KoopmanKernelRegressor(KoopmanRegressor):
     def lift(self, X):
         """regressors.py:104-111."""
         ctx = _lib.get_context()
-        Kout_test = self.kernel.kernel(np.ascontiguousarray(self.training_outputs.T), np.ascontiguousarray(np.asarray(X).T))
+        Xq = np.ascontiguousarray(np.asarray(X, dtype=np.float64).T)
+        cache = self.__dict__.get("_dev_cache")
+        if cache is not None and cache["device"] == ctx.device:
+            import torch
+            Sinv, Ys_d = cache["Sinv"], cache["Ys"]
+            Xq_d = torch.from_numpy(Xq).to(Ys_d.device)
+            Kt = self.kernel.kernel(Ys_d, Xq_d, out=torch.empty((Ys_d.shape[0], Xq.shape[0]), dtype=torch.float64, device=Ys_d.device))
+            out = self._dgemm(ctx, Sinv, Kt, torch.empty_like(Kt))
+            return out.cpu().numpy()
+        Kout_test = self.kernel.kernel(np.ascontiguousarray(self.training_outputs.T), Xq)
         return self._gemm(ctx, self.Kout_sqrt_inv, Kout_test)

@@ -508,3 +508,28 @@ def test_kernel_matrix_bits_do_not_depend_on_the_shape(nk, family, d):
     for rows in (slice(0, 1), slice(3, 8), slice(650, 700)):
         assert np.array_equal(k(A[rows], B), big[rows])   # <= 7500 entries: one thread per entry
     assert np.array_equal(k(A[:40], B[:7]), big[:40, :7])
+
+
+def test_exact_kernel_regressor_device_and_host_compositions_agree(nk, monkeypatch):
+    """KoopmanKernelRegressor.fit keeps its N x N intermediates in HBM (torch tensors as the allocator); the host-composed
+    version (NYSKOOP_EXACT_HOST=1, also the path without torch) runs the same library calls on host arrays."""
+    import pickle
+    rng = np.random.default_rng(5)
+    N = 350
+    x = rng.uniform(-1, 1, (N, 2)); u = rng.uniform(-1, 1, (N, 1))
+    y = x + 0.05 * np.tanh(x @ rng.standard_normal((2, 2))) + 0.05 * u
+    X = np.hstack([x, u])
+    dev = nk.KoopmanKernelRegressor(1, kernel=nk.KernelWrapper([0.7, 0.7]), gamma=1e-6)
+    dev.fit(X, y)
+    assert "_dev_cache" in dev.__dict__  # the device path ran
+    monkeypatch.setenv("NYSKOOP_EXACT_HOST", "1")
+    host = nk.KoopmanKernelRegressor(1, kernel=nk.KernelWrapper([0.7, 0.7]), gamma=1e-6)
+    host.fit(X, y)
+    assert "_dev_cache" not in host.__dict__
+    Xq = X[:40]
+    assert relf(dev.predict(Xq), host.predict(Xq)) < 1e-9
+    assert relf(dev.lift(x[:9].T), host.lift(x[:9].T)) < 1e-10
+    assert relf(dev.weights, host.weights) < 1e-7 and relf(dev.C, host.C) < 1e-7
+    back = pickle.loads(pickle.dumps(dev))  # device tensors do not travel; the copy lifts from its host arrays
+    assert "_dev_cache" not in back.__dict__
+    assert relf(back.predict(Xq), dev.predict(Xq)) < 1e-10
