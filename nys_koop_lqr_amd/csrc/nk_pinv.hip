@@ -592,7 +592,7 @@ int pinv_right_divide(nk_ctx* ctx, const double* P, int64_t ldp, int m, const do
   const double tol = 2.220446049250313e-16 * (double)(m > 64 ? m : 64);  // orthogonality target, above the rounding level
                                                                          // of an m-term dot product
   const int N = m + (m & 1);
-  const int max_sweeps = 60;
+  const int max_sweeps = 150;  // cloth systems: 20-35; a spectrum spread evenly over 17 decades at m = 1000: ~80
   const bool trace = getenv("NYSKOOP_PINV_TRACE") != nullptr;
   // columns this far below the cut-off take no further part (they are dropped, and leaving them unconverged perturbs P by
   // less than 1e-3 eps sigma_max); NYSKOOP_PINV_DEAD overrides the factor for experiments

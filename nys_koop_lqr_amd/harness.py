@@ -33,6 +33,25 @@ def validate_dyn_sys(regressor, true_trajectory, test_controls, relative=False):
     return np.sqrt(np.mean(np.square(true_trajectory - sim)))
 
 
+def validate_dyn_sys_all(regressor, true_trajectories, test_controls, relative=False):
+    """validate_dyn_sys for ALL test trajectories in one device call (the reference loops over them,
+    benchmark_lqr_cloth.py:171-176, benchmark_lqr_hjb.py:296-305): trajectories (k, d, T) with controls (k, p, T) or
+    (k, p, T-1) -> k errors.  The trajectories of a batch do not influence each other (same bits as one call each)."""
+    trajs = np.asarray(true_trajectories, dtype=np.float64)
+    ctrl = np.asarray(test_controls, dtype=np.float64)
+    k, d, T = trajs.shape
+    if ctrl.shape[0] != k or ctrl.shape[2] < T - 1:
+        raise ValueError(f"controls have shape {ctrl.shape}, expected ({k}, p, >= {T - 1})")
+    U = np.zeros((k, T, ctrl.shape[1]))
+    U[:, : min(T, ctrl.shape[2]), :] = np.transpose(ctrl[:, :, :T], (0, 2, 1))
+    if not hasattr(regressor, "_ensure_model"):  # an estimator without a device model (the exact-kernel comparator)
+        return np.array([validate_dyn_sys(regressor, trajs[i], ctrl[i], relative) for i in range(k)])
+    sims = np.transpose(regressor.rollout(np.ascontiguousarray(trajs[:, :, 0]), U), (0, 2, 1))  # (k, d, T)
+    if relative:
+        return np.sqrt(np.sum(np.square(trajs - sims), axis=(1, 2))) / np.sqrt(np.sum(np.square(sims), axis=(1, 2))) * 100
+    return np.sqrt(np.mean(np.square(trajs - sims), axis=(1, 2)))
+
+
 def kfold_slices(n, n_splits=5):
     """sklearn KFold(n_splits) without shuffling (GridSearchCV's default cv): contiguous test folds, the first
     n % n_splits folds one element longer."""

@@ -533,3 +533,16 @@ def test_exact_kernel_regressor_device_and_host_compositions_agree(nk, monkeypat
     back = pickle.loads(pickle.dumps(dev))  # device tensors do not travel; the copy lifts from its host arrays
     assert "_dev_cache" not in back.__dict__
     assert relf(back.predict(Xq), dev.predict(Xq)) < 1e-10
+
+
+@pytest.mark.parametrize("m", [64, 200])
+def test_validate_dyn_sys_all_trajectories_in_one_call(nk, O, m):
+    """The loop over test trajectories (benchmark_lqr_cloth.py:171-176) as one batched rollout: same numbers."""
+    from nys_koop_lqr_amd import harness
+    reg, ref, X, Y, rng = _fitted(nk, O, n=4 * m + 200, d=9, p=2, m=m, seed=40 + m)
+    k, T = 7, 30
+    trajs = rng.standard_normal((k, 9, T)); ctrl = rng.standard_normal((k, 2, T - 1))
+    for relative in (False, True):
+        one_by_one = np.array([harness.validate_dyn_sys(reg, trajs[i], ctrl[i], relative) for i in range(k)])
+        together = harness.validate_dyn_sys_all(reg, trajs, ctrl, relative)
+        assert together.shape == (k,) and np.allclose(together, one_by_one, rtol=1e-12, atol=0)
