@@ -546,3 +546,20 @@ def test_validate_dyn_sys_all_trajectories_in_one_call(nk, O, m):
         one_by_one = np.array([harness.validate_dyn_sys(reg, trajs[i], ctrl[i], relative) for i in range(k)])
         together = harness.validate_dyn_sys_all(reg, trajs, ctrl, relative)
         assert together.shape == (k,) and np.allclose(together, one_by_one, rtol=1e-12, atol=0)
+
+
+@pytest.mark.parametrize("m,block", [(130, "1"), (130, "0"), (600, "1"), (1100, "1")])
+def test_rank_deficient_solve_through_every_jacobi_kernel(nk, O, monkeypatch, m, block):
+    """The minimum-norm solution of an exactly rank-deficient PSD system through the block Jacobi with 8 / 4 / 2 rows per
+    block (m <= 512 / 1024 / 2048) and through the scalar rounds (NYSKOOP_PINV_BLOCK=0), against the oracle's truncated
+    SVD solve with the cut-off inside the spectral gap."""
+    rng = np.random.default_rng(m)
+    r = m - 37
+    Bm = rng.standard_normal((m, r)) / np.sqrt(r)
+    P = Bm @ Bm.T
+    R = rng.standard_normal((m, 3))
+    monkeypatch.setenv("NYSKOOP_PINV_BLOCK", block)
+    X = _solve_spd(nk, P, R)
+    Xo, rank = O.truncated_solve(P, R, rcond=1e-10)
+    assert rank == r
+    assert relf(X, Xo) < 1e-8 and relf(P @ X, P @ Xo) < 1e-8
