@@ -164,7 +164,7 @@ def _fitted(nk, O, n=500, d=12, p=2, m=48, seed=3, ls=4.0, gamma=1e-4):
     return reg, ref, X, Y, rng
 
 
-@pytest.mark.parametrize("m,p", [(48, 2), (100, 6), (128, 6), (129, 3), (200, 1), (33, 0), (520, 6), (1100, 2)])
+@pytest.mark.parametrize("m,p", [(48, 2), (100, 6), (128, 6), (129, 3), (200, 1), (33, 0), (300, 2), (520, 6), (1100, 2)])
 def test_rollout_single_launch_and_stepwise_paths(nk, O, m, p):
     """m <= 128: the whole recursion (and the lift) in one launch with [A | B] resident in the registers of one workgroup;
     larger m: one launch as well, [A | B] spread over ceil(m / 8) workgroups that exchange the state through memory
