@@ -1639,7 +1639,9 @@ static bool chain_mw_wanted(nk_ctx* ctx, const ChainArgs& chain) {
   if (!chain_mw_enabled() || ctx_recording(ctx) || chain.T < 3) return false;
   if (lifted_chain_ok(chain.m, chain.pu, chain.lift ? chain.d : 0)) return false;
   if (!lifted_chain_mw_ok(ctx, chain.m, chain.U ? chain.pu : 0)) return false;
-  return chain.batch <= 16 || (int64_t)chain.batch * chain_mw_workgroups(chain.m) <= ctx->num_cu;
+  const int nt = chain_mw_group(chain.m, chain.batch);
+  const int64_t groups = (chain.batch + nt - 1) / nt;
+  return groups <= 16 || groups * chain_mw_workgroups(chain.m) <= ctx->num_cu;
 }
 
 static bool chain_mw_gave_up(nk_ctx* ctx) {
@@ -1659,8 +1661,11 @@ static int rollout_steps(nk_ctx* ctx, ChainArgs chain, bool z0_in_place, bool us
   if (lifted_chain_ok(m, p, chain.lift ? chain.d : 0)) return launch_lifted_chain(ctx, chain);
   NK_REQUIRE(!chain.lift && z0_in_place, "rollout_steps: internal: the stepwise path needs z_0 in place");
   if (use_mw) {
-    int nb = ctx->num_cu / chain_mw_workgroups(m);  // trajectories that are resident side by side
+    // trajectories that are resident side by side: (CUs / workgroups per trajectory group) groups of `nt`
+    const int nt = chain_mw_group(m, batch);
+    int nb = ctx->num_cu / chain_mw_workgroups(m);
     if (nb < 1) nb = 1;
+    nb *= nt;
     NK_TRY(lifted_chain_mw_reset(ctx));
     for (int b0 = 0; b0 < batch; b0 += nb) {
       ChainArgs sub = chain;

@@ -293,6 +293,7 @@ int launch_lifted_chain(nk_ctx* ctx, const ChainArgs& a);
 // m > 128: multi-workgroup recursion, one launch per group of trajectories that is resident at once (nk_rollout.hip)
 bool lifted_chain_mw_ok(const nk_ctx* ctx, int m, int pu);
 int chain_mw_workgroups(int m);
+int chain_mw_group(int m, int batch);  // trajectories one workgroup advances together
 int launch_lifted_chain_mw(nk_ctx* ctx, const ChainArgs& a);
 int lifted_chain_mw_reset(nk_ctx* ctx);                                       // clears the device status words
 int lifted_chain_mw_fetch_status(nk_ctx* ctx);                                // queues their copy to the host

@@ -267,6 +267,7 @@ struct ChainMwParams {
   const double* bias; int64_t bias_stride;
   double* Zall; int64_t z_stride;                    // [b][t][m]; row 0 holds z_0, rows >= 1 the sentinel
   int T;
+  int batch;                                         // trajectories of the launch (grid.y = ceil(batch / NT))
   int* status;                                       // [0] raised on a timeout, [1..3] = row, step, trajectory of the first
 };
 
@@ -282,65 +283,94 @@ __global__ void mw_sentinel_fill_kernel(double* __restrict__ Zall, int64_t z_str
 // KPT = number of 64-wide chunks of z_t (compile time: the LDS reads and FMAs of a step are straight-line code).  The
 // chunk past m re-reads z[m - 1] (a valid address) and parks zeros.  The controls are a separate term: lane l < pu holds
 // G[r][m + l].
-template <int KPT>
+// NT = trajectories a workgroup advances together (grid.y = ceil(batch / NT)): the rows of G in registers are shared by
+// the NT dot products of a step, so a batch needs NT times fewer workgroups (20 test trajectories at m = 500: 5 x 32
+// workgroups, one launch, where 20 x 32 would not be resident together and went through one GEMM per step).
+template <int KPT, int NT>
 __global__ void __launch_bounds__(64 * MW_ROWS) lifted_chain_mw_kernel(ChainMwParams P) {
-  __shared__ double zs[2][KPT * 64];
+  __shared__ double zs[2][NT][KPT * 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int row = blockIdx.x * MW_ROWS + wave;
   const int m = P.m, pu = P.pu;
   const bool active = row < m;  // idle waves of the last workgroup still fetch their chunks and meet the barriers
-  const int b = blockIdx.y;
+  const int b0 = blockIdx.y * NT;
   double g[KPT];
 #pragma unroll
   for (int j = 0; j < KPT; ++j) {
     const int k = lane + 64 * j;
     g[j] = (active && k < m) ? P.G[(int64_t)row * P.ldg + k] : 0.0;
   }
-  const double* U = (P.U && pu > 0) ? P.U + (int64_t)b * P.u_stride : nullptr;
-  const double gu = (active && U != nullptr && lane < pu) ? P.G[(int64_t)row * P.ldg + m + lane] : 0.0;
-  unsigned long long* zall = reinterpret_cast<unsigned long long*>(P.Zall + (int64_t)b * P.z_stride);
-  const double bias = (active && P.bias) ? P.bias[(int64_t)b * P.bias_stride + row] : 0.0;
+  const bool have_u = P.U != nullptr && pu > 0;
+  const double gu = (active && have_u && lane < pu) ? P.G[(int64_t)row * P.ldg + m + lane] : 0.0;
+  unsigned long long* zall[NT];
+  const double* U[NT];
+  double bias[NT];
+  bool live[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i) {
+    live[i] = b0 + i < P.batch;
+    const int b = live[i] ? b0 + i : b0;  // a padding slot shadows trajectory b0 (reads only)
+    zall[i] = reinterpret_cast<unsigned long long*>(P.Zall + (int64_t)b * P.z_stride);
+    U[i] = have_u ? P.U + (int64_t)b * P.u_stride : nullptr;
+    bias[i] = (active && P.bias) ? P.bias[(int64_t)b * P.bias_stride + row] : 0.0;
+  }
   for (int t = 0; t + 1 < P.T; ++t) {
-    const unsigned long long* zt = zall + (int64_t)t * m;
-    double* buf = zs[t & 1];
-    for (int j = wave; j < KPT; j += MW_ROWS) {  // wave-uniform
-      const int k = lane + 64 * j;
-      const unsigned long long* src = zt + (k < m ? k : m - 1);
-      unsigned long long bits = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (t > 0) {  // z_0 is the caller's data: taken as it is
-        int polls = 0;
-        while (__any(bits == MW_SENTINEL)) {
-          if (++polls >= MW_POLL_LIMIT) {
-            if (lane == 0 && atomicCAS(P.status, 0, 1) == 0) { P.status[1] = row; P.status[2] = t; P.status[3] = b; }
-            bits = MW_QNAN;
-            break;
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      if (!live[i]) continue;  // uniform over the workgroup
+      const unsigned long long* zt = zall[i] + (int64_t)t * m;
+      double* buf = zs[t & 1][i];
+      for (int j = wave; j < KPT; j += MW_ROWS) {  // wave-uniform
+        const int k = lane + 64 * j;
+        const unsigned long long* src = zt + (k < m ? k : m - 1);
+        unsigned long long bits = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t > 0) {  // z_0 is the caller's data: taken as it is
+          int polls = 0;
+          while (__any(bits == MW_SENTINEL)) {
+            if (++polls >= MW_POLL_LIMIT) {
+              if (lane == 0 && atomicCAS(P.status, 0, 1) == 0) { P.status[1] = row; P.status[2] = t; P.status[3] = b0 + i; }
+              bits = MW_QNAN;
+              break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+            bits = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
-          __builtin_amdgcn_s_sleep(1);
-          bits = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        buf[k] = k < m ? __longlong_as_double((long long)bits) : 0.0;  // (0 x an overflowed z[m - 1] would be NaN)
       }
-      buf[k] = k < m ? __longlong_as_double((long long)bits) : 0.0;  // (0 x an overflowed z[m - 1] would be NaN)
     }
-    double a0 = (U != nullptr && lane < pu) ? gu * U[(int64_t)t * pu + lane] : 0.0;
-    double a1 = 0.0;
     // LDS-only barrier (the global store of the previous step need not have retired); the other buffer is free again
     // once every wave has passed THIS barrier, i.e. before anybody writes it in step t + 1
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #pragma unroll
-    for (int j = 0; j < KPT; ++j) {
-      const double v = buf[lane + 64 * j];
-      if (j & 1) a1 = fma(g[j], v, a1);
-      else a0 = fma(g[j], v, a0);
-    }
-    const double acc = wave_sum64_dpp(a0 + a1);
-    if (active && lane == 0) {
-      unsigned long long out = (unsigned long long)__double_as_longlong(acc + bias);
-      if (out == MW_SENTINEL) out = MW_QNAN;
-      __hip_atomic_store(zall + (int64_t)(t + 1) * m + row, out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int i = 0; i < NT; ++i) {
+      if (!live[i]) continue;
+      const double* buf = zs[t & 1][i];
+      double a0 = (have_u && lane < pu) ? gu * U[i][(int64_t)t * pu + lane] : 0.0;
+      double a1 = 0.0;
+#pragma unroll
+      for (int j = 0; j < KPT; ++j) {
+        const double v = buf[lane + 64 * j];
+        if (j & 1) a1 = fma(g[j], v, a1);
+        else a0 = fma(g[j], v, a0);
+      }
+      const double acc = wave_sum64_dpp(a0 + a1);
+      if (active && lane == 0) {
+        unsigned long long out = (unsigned long long)__double_as_longlong(acc + bias[i]);
+        if (out == MW_SENTINEL) out = MW_QNAN;
+        __hip_atomic_store(zall[i] + (int64_t)(t + 1) * m + row, out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
   }
 }
 
+// trajectories per workgroup for a batch: NT * ceil(m / 64) <= 32 (the LDS image of the NT state vectors, two buffers)
+int chain_mw_group(int m, int batch) {
+  const int kpt = (m + 63) / 64;
+  int nt = 1;
+  while (nt < 4 && 2 * nt * (kpt <= 4 ? 4 : kpt <= 8 ? 8 : kpt <= 16 ? 16 : 32) <= 32 && 2 * nt <= batch) nt *= 2;
+  return nt;
+}
 int chain_mw_workgroups(int m) { return (m + MW_ROWS - 1) / MW_ROWS; }
 bool lifted_chain_mw_ok(const nk_ctx* ctx, int m, int pu) {
   return m >= 1 && m <= 64 * MW_KPT && pu >= 0 && pu <= 64 && chain_mw_workgroups(m) <= ctx->num_cu;
@@ -352,23 +382,32 @@ bool lifted_chain_mw_ok(const nk_ctx* ctx, int m, int pu) {
 int launch_lifted_chain_mw(nk_ctx* ctx, const ChainArgs& a) {
   NK_REQUIRE(lifted_chain_mw_ok(ctx, a.m, a.U ? a.pu : 0), "lifted_chain_mw: operators do not fit");
   NK_REQUIRE(a.batch >= 1 && a.T >= 1 && !a.lift && a.z0 == nullptr, "lifted_chain_mw: z_0 must be in place");
-  NK_REQUIRE((int64_t)a.batch * chain_mw_workgroups(a.m) <= ctx->num_cu, "lifted_chain_mw: more workgroups than CUs");
+  const int nt = chain_mw_group(a.m, a.batch);
+  const int groups = (a.batch + nt - 1) / nt;
+  NK_REQUIRE((int64_t)groups * chain_mw_workgroups(a.m) <= ctx->num_cu, "lifted_chain_mw: more workgroups than CUs");
   if (a.T < 2) return NK_OK;
   const int pu = a.U ? a.pu : 0;
   ChainMwParams P;
   P.G = a.G; P.ldg = a.ldg; P.m = a.m; P.pu = pu; P.kpt = (a.m + 63) / 64; P.U = pu > 0 ? a.U : nullptr;
   P.u_stride = a.u_stride; P.bias = a.bias; P.bias_stride = a.bias_stride; P.Zall = a.Zall; P.z_stride = a.z_stride;
-  P.T = a.T; P.status = ctx->d_info + 12;
+  P.T = a.T; P.batch = a.batch; P.status = ctx->d_info + 12;
   const int64_t total = (int64_t)a.batch * (a.T - 1) * a.m;
   int64_t blocks = (total + 255) / 256;
   if (blocks > 1024) blocks = 1024;
   hipLaunchKernelGGL(mw_sentinel_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, a.Zall, a.z_stride, a.m,
                      a.T, a.batch);
-  const dim3 grid((unsigned)chain_mw_workgroups(a.m), (unsigned)a.batch), block(64 * MW_ROWS);
-  if (P.kpt <= 4) hipLaunchKernelGGL(lifted_chain_mw_kernel<4>, grid, block, 0, ctx->stream, P);
-  else if (P.kpt <= 8) hipLaunchKernelGGL(lifted_chain_mw_kernel<8>, grid, block, 0, ctx->stream, P);
-  else if (P.kpt <= 16) hipLaunchKernelGGL(lifted_chain_mw_kernel<16>, grid, block, 0, ctx->stream, P);
-  else hipLaunchKernelGGL(lifted_chain_mw_kernel<MW_KPT>, grid, block, 0, ctx->stream, P);
+  const dim3 grid((unsigned)chain_mw_workgroups(a.m), (unsigned)groups), block(64 * MW_ROWS);
+#define NK_MW_LAUNCH(K, N) hipLaunchKernelGGL((lifted_chain_mw_kernel<K, N>), grid, block, 0, ctx->stream, P)
+  if (P.kpt <= 4) {
+    if (nt == 4) NK_MW_LAUNCH(4, 4); else if (nt == 2) NK_MW_LAUNCH(4, 2); else NK_MW_LAUNCH(4, 1);
+  } else if (P.kpt <= 8) {
+    if (nt == 4) NK_MW_LAUNCH(8, 4); else if (nt == 2) NK_MW_LAUNCH(8, 2); else NK_MW_LAUNCH(8, 1);
+  } else if (P.kpt <= 16) {
+    if (nt == 2) NK_MW_LAUNCH(16, 2); else NK_MW_LAUNCH(16, 1);
+  } else {
+    NK_MW_LAUNCH(MW_KPT, 1);
+  }
+#undef NK_MW_LAUNCH
   NK_HIP(hipGetLastError());
   return NK_OK;
 }
