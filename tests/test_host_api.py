@@ -109,3 +109,16 @@ def test_host_dlqr_matches_shipped_gain(golden):
     Q = 0.005 * reg.C.T @ reg.C
     K, _ = dlqr(reg.A, reg.B, (Q + Q.T) / 2, np.eye(6))
     assert relf(cloth_gain_for_simulator(K), g["K_lqr_seed_1"]) < 5e-3
+
+
+def test_every_environment_switch_is_documented():
+    """Every NYSKOOP_* variable the library or the package reads is listed in INTEGRATION.md (section 6)."""
+    import glob
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    names = set()
+    for path in glob.glob(os.path.join(root, "nys_koop_lqr_amd", "csrc", "*.h*")) + glob.glob(os.path.join(root, "nys_koop_lqr_amd", "*.py")):
+        names.update(re.findall(r"NYSKOOP_[A-Z0-9_]+", open(path).read()))
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    missing = sorted(n for n in names if n not in doc and n not in ("NYSKOOP_BENCH_BACKEND",))
+    assert not missing, f"undocumented environment switches: {missing}"
