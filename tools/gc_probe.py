@@ -1,5 +1,5 @@
 import gc, os, sys, time
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import nys_koop_lqr_amd as nk
 rng = np.random.default_rng(0)
