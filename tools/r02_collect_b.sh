@@ -20,6 +20,14 @@ NYSKOOP_CHAIN_MW=0 python3 tools/chain_mw_probe.py 500,6,6 2000,8,6 > $O/chain_m
 NYSKOOP_HOST_PASSES=1 python3 tools/host_fit_bench.py > $O/host_fit_bench.log 2>&1
 python3 tools/host_fit_bench.py >> $O/host_fit_bench.log 2>&1
 python3 tools/cv_bench.py > $O/cv_bench.log 2>&1
+python3 tools/jacobi_bench.py > $O/jacobi_bench.log 2>&1
+NYSKOOP_PINV_BLOCK=0 python3 tools/jacobi_bench.py >> $O/jacobi_bench.log 2>&1
+python3 tools/exact_kernel_bench.py 4000 > $O/exact_kernel_bench.log 2>&1
+NYSKOOP_EXACT_HOST=1 python3 tools/exact_kernel_bench.py 4000 >> $O/exact_kernel_bench.log 2>&1
+python3 tools/exact_kernel_bench.py 10000 >> $O/exact_kernel_bench.log 2>&1
+NYSKOOP_EXACT_HOST=1 python3 tools/exact_kernel_bench.py 10000 >> $O/exact_kernel_bench.log 2>&1
+python3 tools/kmat_epilogue_probe.py > $O/kmat_epilogue_probe.log 2>&1
+python3 tools/rollout_fuzz.py 80 > $O/rollout_fuzz.log 2>&1
 python3 tools/soak.py 30 > $O/soak.log 2>&1
 python3 tools/shape_sweep.py 32 > $O/shape_sweep.log 2>&1
 tail -4 $O/lockstep_bench.log | cut -c1-150; grep "^m=" $O/rollout_bench.log | cut -c1-300; grep PASSES $O/host_fit_bench.log; tail -3 $O/soak.log; tail -3 $O/shape_sweep.log

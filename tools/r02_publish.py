@@ -19,7 +19,9 @@ for src, dst in (("bench_line.json", "r02_bench_line.json"), ("bench_line_profil
                  ("rollout_bench.log", "r02_rollout_bench.log"), ("chain_mw_probe.log", "r02_chain_mw_probe.log"),
                  ("chain_mw_probe_stepwise.log", "r02_chain_mw_probe_stepwise.log"),
                  ("host_fit_bench.log", "r02_host_fit_bench.log"), ("soak.log", "r02_soak.log"),
-                 ("shape_sweep.log", "r02_shape_sweep.log")):
+                 ("shape_sweep.log", "r02_shape_sweep.log"), ("jacobi_bench.log", "r02_jacobi_bench.log"),
+                 ("exact_kernel_bench.log", "r02_exact_kernel_bench.log"), ("kmat_epilogue_probe.log", "r02_kmat_epilogue_probe.log"),
+                 ("rollout_fuzz.log", "r02_rollout_fuzz.log")):
     cp(src, dst)
 for i in (1, 2, 3):
     cp(f"pmc_gram_{i}/run_counter_collection.csv", f"r02_pmc_gram_{i}.csv")
