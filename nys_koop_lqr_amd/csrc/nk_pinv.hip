@@ -50,6 +50,19 @@ __device__ __forceinline__ void rr_pair(int N, int r, int k, int* a, int* b) {
 }
 
 constexpr int JAC_KPT = 8;  // entries of a row per thread held in registers (m <= 2048)
+// Rotation that makes two rows with squared norms a, b and inner product c orthogonal.  False: leave the pair alone (one of
+// them is below the dead-column threshold, or they are orthogonal to `tol` already: c^2 <= tol^2 a b, tested without square
+// roots).  The dependent chain is what an inner round of the block kernel waits for: one division, one square root, one
+// more division and one reciprocal square root.
+__device__ __forceinline__ bool jacobi_rotation(double a, double b, double c, double tol, double small2, double* cs, double* sn) {
+  if (a < small2 || b < small2 || c == 0.0 || !(c * c > (tol * tol) * a * b)) return false;
+  const double zeta = (b - a) / (2.0 * c);
+  const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(fma(zeta, zeta, 1.0)));
+  *cs = rsqrt(fma(t, t, 1.0));
+  *sn = *cs * t;
+  return true;
+}
+
 __device__ __forceinline__ void jacobi_round_kernel_body(double* __restrict__ W, double* __restrict__ V, int m, int N, int round, double tol, const double* __restrict__ d_small2, int* __restrict__ rot_count) {
   __shared__ double sh[3][4];
   __shared__ double cs_sn[2];
@@ -99,13 +112,7 @@ __device__ __forceinline__ void jacobi_round_kernel_body(double* __restrict__ W,
     b = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
     c = sh[2][0] + sh[2][1] + sh[2][2] + sh[2][3];
     double cs = 1.0, sn = 0.0;
-    const double small2 = d_small2[0];
-    const bool dead = a < small2 || b < small2;  // a column below the cut-off takes no further part
-    if (!dead && c != 0.0 && fabs(c) > tol * sqrt(a) * sqrt(b)) {
-      const double zeta = (b - a) / (2.0 * c);
-      const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-      cs = 1.0 / sqrt(1.0 + t * t);
-      sn = cs * t;
+    if (jacobi_rotation(a, b, c, tol, d_small2[0], &cs, &sn)) {  // (a column below the cut-off takes no further part)
       rot_count[blockIdx.x] += 1;  // one slot per pair of the round: no contended atomic (250 same-address atomics from
                                    // all XCDs cost ~25 us per launch, more than everything else in the round)
     }
@@ -175,13 +182,8 @@ __device__ __forceinline__ void jacobi_round_wave_kernel_body(double* __restrict
     c = fma(x[j], y[j], c);
   }
   a = wave_allsum_p(a); b = wave_allsum_p(b); c = wave_allsum_p(c);
-  const double small2 = d_small2[0];
-  const bool dead = a < small2 || b < small2;  // a column below the cut-off takes no further part
-  if (dead || c == 0.0 || !(fabs(c) > tol * sqrt(a) * sqrt(b))) return;  // wave-uniform
-  const double zeta = (b - a) / (2.0 * c);
-  const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-  const double cs = 1.0 / sqrt(1.0 + t * t);
-  const double sn = cs * t;
+  double cs = 1.0, sn = 0.0;
+  if (!jacobi_rotation(a, b, c, tol, d_small2[0], &cs, &sn)) return;  // wave-uniform
   if (lane == 0) rot_count[pair] += 1;  // one slot per pair of the round (see jacobi_round_kernel)
   if (sn == 0.0) return;
 #pragma unroll
@@ -252,12 +254,8 @@ __device__ __forceinline__ void jacobi_sweep_kernel_body(double* __restrict__ W,
         c = fma(x[j], y[j], c);
       }
       a = wave_allsum_p(a); b = wave_allsum_p(b); c = wave_allsum_p(c);
-      const bool dead = a < small2 || b < small2;
-      if (!dead && c != 0.0 && fabs(c) > tol * sqrt(a) * sqrt(b)) {
-        const double zeta = (b - a) / (2.0 * c);
-        const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-        const double cs = 1.0 / sqrt(1.0 + t * t);
-        const double sn = cs * t;
+      double cs = 1.0, sn = 0.0;
+      if (jacobi_rotation(a, b, c, tol, small2, &cs, &sn)) {
         ++rotations;
         if (sn != 0.0) {
 #pragma unroll
@@ -356,12 +354,8 @@ __device__ __forceinline__ void jacobi_block_body(double* __restrict__ W, double
         c = fma(x[j], y[j], c);
       }
       a = wave_allsum_p(a); b = wave_allsum_p(b); c = wave_allsum_p(c);
-      const bool dead = a < small2 || b < small2;
-      if (!dead && c != 0.0 && fabs(c) > tol * sqrt(a) * sqrt(b)) {
-        const double zeta = (b - a) / (2.0 * c);
-        const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-        const double cs = 1.0 / sqrt(1.0 + t * t);
-        const double sn = cs * t;
+      double cs = 1.0, sn = 0.0;
+      if (jacobi_rotation(a, b, c, tol, small2, &cs, &sn)) {
         ++rotations;
         if (sn != 0.0) {
           double* vp = Vs + p * LDW;
