@@ -143,6 +143,15 @@ int nk_cv_grid(nk_ctx* const* members, int32_t n_members, const double* X, int64
 int nk_group_enter(nk_ctx* member);
 int nk_group_leave(nk_ctx* member);
 int nk_group_stats(nk_ctx* member, uint64_t* out4);
+/* Process-wide counters of the slow paths that are otherwise silent (they cost time, never correctness):
+ *   out[0] single-launch lifted recursions (nk_rollout / nk_closed_loop*, 128 < m <= 2048) that gave up waiting for a
+ *          workgroup that was not resident and were repeated with one launch per step (5-10x slower);
+ *   out[1] single-launch Jacobi sweeps (rank-truncating branch of the fit inside a lock-step group) that gave up the
+ *          same way and finished with one launch per round;
+ *   out[2] fits whose regularised system(s) took the rank-truncating branch (regressors.py:155,165: lstsq / gelsd);
+ *   out[3] fits that repeated the matrix square root with the factorisation-free iteration.
+ * n = number of entries the caller provides (<= 4 are written). */
+int nk_runtime_counters(uint64_t* out, int32_t n);
 /* Releases everything the library still holds on every device -- live contexts (their streams, events and workspaces),
  * live models, the model-buffer pool and page-locked host blocks -- after waiting for pending work.  Handles that were
  * live become invalid; destroying them afterwards is a harmless no-op, so language bindings may call this from an

@@ -65,6 +65,7 @@ SIGNATURES = {
     "nk_group_enter": (C.c_int, [_P]),
     "nk_group_leave": (C.c_int, [_P]),
     "nk_group_stats": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
+    "nk_runtime_counters": (C.c_int, [C.POINTER(C.c_uint64), C.c_int32]),
     "nk_cv_grid": (C.c_int, [C.POINTER(_P), _I32, _P, _I64, _P, _I64, _I64, _I32, _I32, C.POINTER(CvUnit), _I32,
                              C.POINTER(_D), C.POINTER(_I32)]),
     "nk_host_alloc": (_P, [C.c_uint64]),
@@ -162,6 +163,15 @@ def shutdown():
 def check(rc):
     if rc != NK_OK:
         raise NyskoopError(rc, load_library().nk_last_error().decode("utf-8", "replace"))
+
+
+def runtime_counters():
+    """Process-wide counts of the library's silent slow paths (nk_runtime_counters): single-launch recursions and Jacobi
+    sweeps that gave up waiting for non-resident workgroups, fits that took the rank-truncating branch of the
+    reference's lstsq (regressors.py:155,165), fits that repeated the matrix square root."""
+    v = (C.c_uint64 * 4)()
+    check(load_library().nk_runtime_counters(v, 4))
+    return dict(chain_giveups=int(v[0]), jacobi_giveups=int(v[1]), rank_truncated_fits=int(v[2]), sqrt_retries=int(v[3]))
 
 
 def torch_if_cuda():

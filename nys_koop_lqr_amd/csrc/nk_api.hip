@@ -552,7 +552,15 @@ int nk_group_enter(nk_ctx* ctx) {
 int nk_group_leave(nk_ctx* ctx) {
   NK_REQUIRE(ctx != nullptr, "nk_group_leave: null context");
   tl_ctx = ctx;
-  return group_leave(ctx);
+  const int rc = group_leave(ctx);
+  tl_ctx = nullptr;  // the thread is outside the unit: nothing it does next may be recorded for (or wait on) this member
+  return rc;
+}
+
+int nk_runtime_counters(uint64_t* out, int32_t n) {
+  NK_REQUIRE(out != nullptr && n >= 0, "nk_runtime_counters: bad argument");
+  for (int i = 0; i < n && i < CNT_N; ++i) out[i] = nk::read_counter(i);
+  return NK_OK;
 }
 
 int nk_group_stats(nk_ctx* ctx, uint64_t* out4) {
@@ -653,6 +661,9 @@ int nk_cv_grid(nk_ctx* const* members, int32_t n_members, const double* X, int64
             rc = nk_score_neg_rmse(ctx, mdl, Xd + cu.test_begin * ldxd, ldxd, Yd + cu.test_begin * ldyd, ldyd,
                                    cu.test_end - cu.test_begin, &sc);
           if (mdl) nk_model_destroy(mdl);
+          tl_ctx = ctx;
+          const int rc_leave = group_leave(ctx);  // flushes what the unit recorded after its last synchronisation
+          if (rc == NK_OK) rc = rc_leave;
           if (rc == NK_ERR_NOT_SPD && defer_rank_deficient) {
             std::lock_guard<std::mutex> lk(deferred_mu);
             deferred.push_back(u);
@@ -660,8 +671,6 @@ int nk_cv_grid(nk_ctx* const* members, int32_t n_members, const double* X, int64
             scores[u] = rc == NK_OK ? sc : std::nan("");
             if (status) status[u] = rc;
           }
-          tl_ctx = ctx;
-          (void)group_leave(ctx);
         }
         round.wait(B);
       }
@@ -1235,11 +1244,13 @@ static int fit_impl(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int6
       }
       rank_sys[q] = pi.rank;
     }
+    count_event(CNT_RANK_TRUNCATED);
     redo_products = true;
   }
   {
     const int vr = sqrtm_verdict(ctx, &splan, &it, &resid);  // the iteration was queued without host round trips
     if (vr == NK_SQRT_RETRY) {
+      count_event(CNT_SQRT_RETRY);
       // K_mm + jitter I is not positive definite to working precision (or the eigenvalue bound did not hold): the
       // coupled iteration needs no factorisation; then everything that depends on the square root once more
       NK_TRY(sqrtm_spd_coupled(ctx, Kj, m, m, mdl->S, mdl->Sinv, &it, &resid));
@@ -1455,6 +1466,12 @@ int nk_model_get_ops_async(nk_ctx* ctx, nk_model* mdl, double* G, int64_t ldg, d
   if (G) NK_HIP(copy(G, ldg, mdl->A, mp, m, mp));
   if (Cm) NK_HIP(copy(Cm, ldc, mdl->C, m, d, m));
   if (W) NK_HIP(copy(W, ldw, mdl->W, mp, d, mp));
+  if (ctx_recording(ctx)) {
+    // member of a lock-step group: the copies above were RECORDED in this member's sequence and no event exists that
+    // another thread could wait on, so the fetch completes here (one flush), and nothing is left pending on the model
+    NK_HIP(hipStreamSynchronize(ctx->stream));
+    return NK_OK;
+  }
   hipEvent_t ev = nullptr;
   NK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
   hipError_t e = hipEventRecord(ev, ctx->stream_copy);
@@ -1481,7 +1498,10 @@ int nk_model_wait(nk_model* mdl) {
 
 static int model_wait_unchecked(nk_model* mdl) {
   if (mdl->ev_fetch) {
-    hipError_t e = hipEventSynchronize(mdl->ev_fetch);
+    // the REAL wait, whatever context the calling thread last used: a pending fetch is always a recorded event on a
+    // copy stream (fetches by group members complete inside nk_model_get_ops_async), so this must not be turned into a
+    // round barrier of the caller's group
+    hipError_t e = real_event_sync(mdl->ev_fetch);
     (void)hipEventDestroy(mdl->ev_fetch);
     mdl->ev_fetch = nullptr;
     if (e != hipSuccess) {
@@ -1648,8 +1668,11 @@ static bool chain_mw_gave_up(nk_ctx* ctx) {
   int row = 0, step = 0, traj = 0;
   if (!lifted_chain_mw_timed_out(ctx, &row, &step, &traj)) {
     const char* hook = getenv("NYSKOOP_CHAIN_MW_TEST_GIVEUP");  // test hook: pretend the wait gave up (tests/)
-    return hook != nullptr && hook[0] == '1';
+    const bool forced = hook != nullptr && hook[0] == '1';
+    if (forced) count_event(CNT_CHAIN_GIVEUP);
+    return forced;
   }
+  count_event(CNT_CHAIN_GIVEUP);
   if (getenv("NYSKOOP_TRACE"))
     fprintf(stderr, "[nyskoop] single-launch recursion timed out (row %d, step %d, trajectory %d): repeating stepwise\n", row,
             step, traj);

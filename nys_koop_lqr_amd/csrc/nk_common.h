@@ -132,7 +132,12 @@ void group_detach(nk_ctx* c);
 int group_enter(nk_ctx* c);
 int group_leave(nk_ctx* c);
 void group_stats(nk_ctx* c, uint64_t out[4]);
+// slow-path counters (nk_runtime_counters)
+enum { CNT_CHAIN_GIVEUP = 0, CNT_JACOBI_GIVEUP = 1, CNT_RANK_TRUNCATED = 2, CNT_SQRT_RETRY = 3, CNT_N = 4 };
+void count_event(int which);
+uint64_t read_counter(int which);
 hipError_t real_stream_sync(hipStream_t s);
+hipError_t real_event_sync(hipEvent_t e);
 
 // ---- workspace -------------------------------------------------------------------------------------------
 int arena_reset(nk_ctx* ctx);

@@ -15,6 +15,7 @@
 //   * partial tiles go to a slab [tile][slice][128][128]; a second kernel sums the slices in a fixed order and
 //     applies alpha/beta, bounds and the symmetric mirror (deterministic; no float atomics).
 #include "nk_common.h"
+#include "nk_tn_kstep.inc"
 
 #include <cstdlib>
 #include <cstring>
@@ -53,6 +54,7 @@ struct TnParams {
   int nprob;
   int ntiles;
   int K, splitk, klen;
+  int kmask;            // experiments only (NYSKOOP_TN_KMASK): operand rows are fetched from k & kmask; -1 = off
   const double* zeros;  // >= 1 KiB of zeros
   double* slab;
   // conditional launch (device-side early exit of an iteration that has already converged, no host round trip): the
@@ -71,10 +73,28 @@ struct TnParams {
   double sigma0sq;
 };
 
-__device__ __forceinline__ void dma_row(const double* gsrc, double* lds_row) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                   (__attribute__((address_space(3))) void*)lds_row, 16, 0, 0);
+__device__ __forceinline__ uint64_t uniform_u64(uint64_t v) {
+  // (the builtin returns a signed int: without the casts the low word would be sign-extended into the high one)
+  return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)) << 32) |
+         (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)v);
 }
+// One LDS-DMA instruction: the wave's 64 lanes move 16 bytes each from gsrc (per lane) to lds_row + 16 * lane.
+// Issued through inline assembly on purpose: the compiler models the builtin as a FLAT access that may touch LDS
+// ("pending flat"), after which every LDS wait it inserts degrades to lgkmcnt(0) -- which would stall the MFMA
+// stream on the operand prefetch issued just before.  Hidden from its model, the waits on ds_read stay exact; the
+// price is that the vmcnt wait before the stage barrier is ours to place (dma_wait_all).
+__device__ __forceinline__ void dma_row(const double* row_base, uint32_t lane_off_bytes, uint32_t lds_addr) {
+  // row_base is wave-uniform (scalar register pair), the per-lane part is a 32-bit byte offset, lds_addr the LDS byte
+  // address of the destination row (wave-uniform): in the steady state the whole address stream of a k-step is a
+  // handful of SALU instructions, no VALU
+  // (the batched twins read their parameters from a device table: make the uniformity explicit)
+  const uint64_t rbu = uniform_u64((uint64_t)(uintptr_t)row_base);
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+               :
+               : "v"(lane_off_bytes), "s"(rbu), "s"((uint32_t)__builtin_amdgcn_readfirstlane(lds_addr))
+               : "m0");
+}
+__device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // tile (tm, tn) of index t within a problem.  Full problems whose tile grid is a multiple of 8 x 8 are walked in 8 x 8
 // super-blocks: workgroups are dispatched in index order, so the ~64 tiles an XCD holds at a time then stream 8 + 8
@@ -170,25 +190,37 @@ __device__ __forceinline__ void tn_body(const TnParams& P) {
   if (pr.ktrim == KTRIM_A_LOWER) kbeg = max(kbeg, tm * TBM);        // A[k][i] = 0 for i > k
   const int ktiles = kend > kbeg ? (kend - kbeg + TBK - 1) / TBK : 0;
 
-  // per-lane source columns (2 doubles per lane), clamped into the valid, 16-byte aligned range
-  const int ca = min(tm * TBM + lane * 2, (pr.M - 1) & ~1);
-  const int cb = min(tn * TBM + lane * 2, (pr.N - 1) & ~1);
-  const double* zsrc = P.zeros + lane * 2;
+  // per-lane source columns (2 doubles per lane), clamped into the valid, 16-byte aligned range, as byte offsets
+  const uint32_t offa = (uint32_t)min(tm * TBM + lane * 2, (pr.M - 1) & ~1) * 8u;
+  const uint32_t offb = (uint32_t)min(tn * TBM + lane * 2, (pr.N - 1) & ~1) * 8u;
+  const uint32_t offz = (uint32_t)lane * 16u;
 
   // wave w moves k-rows w, w+4, w+8, w+12 of the A panel and of the B panel
+  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;  // low half of a generic LDS address = the LDS byte address
   auto issue = [&](int kt, int stage) {
-    double* sa = smem + stage * TSTAGE;
-    double* sb = sa + TBK * TSTRIDE;
+    const uint32_t sa = lds0 + (uint32_t)(stage * TSTAGE) * 8u;
+    const uint32_t sb = sa + (uint32_t)(TBK * TSTRIDE) * 8u;
     const int k0 = kbeg + kt * TBK;
+    if (k0 + TBK <= kend) {  // all 16 rows inside the K range (every step but the last of a slice)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int r = wave + 4 * q;
-      const int k = k0 + r;
-      const bool ok = k < kend;
-      const double* ga = ok ? opA + (int64_t)k * pr.lda + ca : zsrc;
-      const double* gb = ok ? opB + (int64_t)k * pr.ldb + cb : zsrc;
-      dma_row(ga, sa + r * TSTRIDE);
-      dma_row(gb, sb + r * TSTRIDE);
+      for (int q = 0; q < 4; ++q) {
+        const int r = wave + 4 * q;
+        dma_row(opA + (int64_t)((k0 + r) & P.kmask) * pr.lda, offa, sa + (uint32_t)(r * TSTRIDE) * 8u);
+        dma_row(opB + (int64_t)((k0 + r) & P.kmask) * pr.ldb, offb, sb + (uint32_t)(r * TSTRIDE) * 8u);
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int r = wave + 4 * q;
+        const int k = k0 + r;
+        if (k < kend) {
+          dma_row(opA + (int64_t)k * pr.lda, offa, sa + (uint32_t)(r * TSTRIDE) * 8u);
+          dma_row(opB + (int64_t)k * pr.ldb, offb, sb + (uint32_t)(r * TSTRIDE) * 8u);
+        } else {  // rows past the K range come from the zero page
+          dma_row(P.zeros, offz, sa + (uint32_t)(r * TSTRIDE) * 8u);
+          dma_row(P.zeros, offz, sb + (uint32_t)(r * TSTRIDE) * 8u);
+        }
+      }
     }
   };
 
@@ -201,30 +233,90 @@ __device__ __forceinline__ void tn_body(const TnParams& P) {
   const int wm = wave >> 1, wn = wave & 1;
   const int r16 = lane & 15, g4 = lane >> 4;
 
-  if (ktiles > 0) issue(0, 0);
-  for (int kt = 0; kt < ktiles; ++kt) {
-    const int st = kt & 1;
-    // my DMAs for step kt have landed; after the barrier everybody's have, and everybody is done reading stage st^1
+  // Operand fragments of k-sub-step ks (4 contraction rows) of a stage: 4 + 4 ds_read_b64 per lane.
+  auto frag = [&](int stage, int ks, double (&a)[4], double (&b)[4]) {
+    const double* a_base = smem + stage * TSTAGE + wm * 64 + r16 + (ks * 4 + g4) * TSTRIDE;
+    const double* b_base = a_base + TBK * TSTRIDE + (wn - wm) * 64;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = a_base[i * 16];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b[j] = b_base[j * 16];
+  };
+  auto mma = [&](const double (&a)[4], const double (&b)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+  };
+  // Software pipeline.  Two waves share a SIMD's matrix pipe and the arbiter alternates between them, which keeps two
+  // waves that run the same loop in phase: whatever one of them does outside its MFMA stream (LDS waits, DMA issue and
+  // its address arithmetic), the other does at the same moment, and the pipe idles for all of it.  So (1) the fragments
+  // of sub-step ks + 1 are fetched into a second register set while the 16 MFMAs of sub-step ks are issued, the
+  // step's single barrier sits inside the LAST sub-step (by then this wave has read all of the current stage, and the
+  // DMA of the next stage, issued three MFMA blocks earlier, has landed) and the first fragments of the next step are
+  // fetched across it; (2) the steady-state step is ONE hand-scheduled assembly block (nk_tn_kstep.inc, generated by
+  // tools/gen_tn_kstep.py) in which every non-matrix instruction sits in a gap between two MFMAs.  The C++ form of the
+  // same step below (compiler-scheduled) runs the last step(s) of a K range, whose DMA needs row checks.
+  double a0[4], b0[4], a1[4], b1[4];
+  if (ktiles > 0) {
+    issue(0, 0);
+    dma_wait_all();
     __syncthreads();
-    const double* a_base = smem + st * TSTAGE + wm * 64 + r16;
-    const double* b_base = smem + st * TSTAGE + TBK * TSTRIDE + wn * 64 + r16;
-#pragma unroll
-    for (int ks = 0; ks < TBK / 4; ++ks) {
-      double a[4], b[4];
-      const int krow = (ks * 4 + g4) * TSTRIDE;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) a[i] = a_base[krow + i * 16];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) b[j] = b_base[krow + j * 16];
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
-      // the DMA for the next step is issued in the shadow of the first 16 MFMAs (the matrix pipe is busy for 1024
-      // cycles; address arithmetic and the 8 LDS-DMA instructions issue meanwhile)
-      if (ks == 0 && kt + 1 < ktiles) issue(kt + 1, st ^ 1);
-    }
+    frag(0, 0, a0, b0);
+  }
+  // LDS read addresses of the fragments (byte addresses; stage 1 = stage 0 + one stage)
+  const uint32_t ard0 = lds0 + (uint32_t)(wm * 64 + r16 + g4 * TSTRIDE) * 8u;
+  const uint32_t brd0 = lds0 + (uint32_t)(TBK * TSTRIDE + wn * 64 + r16 + g4 * TSTRIDE) * 8u;
+  constexpr uint32_t STAGE_B = (uint32_t)TSTAGE * 8u;
+  const uint32_t stra = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(pr.lda * 32));  // 4 rows, in bytes
+  const uint32_t strb = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(pr.ldb * 32));
+  // steady steps: kt = 0 .. nfull - 2 (step kt issues the DMA of step kt + 1, which must be a full step); the assembly
+  // loop takes them two at a time (LDS stage 0, then 1)
+  const int nfull = (kend - kbeg) / TBK;
+  int kt_start = 0;
+  if (P.kmask == -1 && nfull >= 3) {
+    uint32_t cnt = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)((nfull - 1) / 2));
+    kt_start = 2 * (int)cnt;
+    const uint64_t rowa = uniform_u64((uint64_t)(uintptr_t)(opA + (int64_t)(kbeg + TBK + wave) * pr.lda));
+    const uint64_t rowb = uniform_u64((uint64_t)(uintptr_t)(opB + (int64_t)(kbeg + TBK + wave) * pr.ldb));
+    const uint32_t dst0 = (uint32_t)__builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(wave * TSTRIDE) * 8u);
+    const uint32_t dst1 = dst0 + STAGE_B;
+    const uint32_t ard1 = ard0 + STAGE_B, brd1 = brd0 + STAGE_B;
+    asm volatile(NK_TN_KLOOP_ASM
+                 : [c00] "+v"(acc[0][0]), [c01] "+v"(acc[0][1]), [c02] "+v"(acc[0][2]), [c03] "+v"(acc[0][3]),
+                   [c10] "+v"(acc[1][0]), [c11] "+v"(acc[1][1]), [c12] "+v"(acc[1][2]), [c13] "+v"(acc[1][3]),
+                   [c20] "+v"(acc[2][0]), [c21] "+v"(acc[2][1]), [c22] "+v"(acc[2][2]), [c23] "+v"(acc[2][3]),
+                   [c30] "+v"(acc[3][0]), [c31] "+v"(acc[3][1]), [c32] "+v"(acc[3][2]), [c33] "+v"(acc[3][3]),
+                   [a00] "+v"(a0[0]), [a01] "+v"(a0[1]), [a02] "+v"(a0[2]), [a03] "+v"(a0[3]),
+                   [b00] "+v"(b0[0]), [b01] "+v"(b0[1]), [b02] "+v"(b0[2]), [b03] "+v"(b0[3]),
+                   [a10] "=&v"(a1[0]), [a11] "=&v"(a1[1]), [a12] "=&v"(a1[2]), [a13] "=&v"(a1[3]),
+                   [b10] "=&v"(b1[0]), [b11] "=&v"(b1[1]), [b12] "=&v"(b1[2]), [b13] "=&v"(b1[3]), [cnt] "+s"(cnt)
+                 : [ard0] "v"(ard0), [brd0] "v"(brd0), [ard1] "v"(ard1), [brd1] "v"(brd1), [voa] "v"(offa), [vob] "v"(offb),
+                   [rowa] "s"(rowa), [rowb] "s"(rowb), [stra] "s"(stra), [strb] "s"(strb), [dst0] "s"(dst0), [dst1] "s"(dst1)
+                 : "memory", "m0", "scc", "s92", "s93", "s94", "s95");
+  }
+  for (int kt = kt_start; kt < ktiles; ++kt) {
+    const int st = kt & 1;
+    const bool more = kt + 1 < ktiles;
+    frag(st, 1, a1, b1);
+    if (more) issue(kt + 1, st ^ 1);  // everybody left stage st^1 at the barrier of the previous step
+    mma(a0, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    frag(st, 2, a0, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(a1, b1);
+    __builtin_amdgcn_sched_barrier(0);
+    frag(st, 3, a1, b1);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(a0, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    dma_wait_all();
+    __syncthreads();  // (waits for this wave's LDS reads as well)
+    if (more) frag(st ^ 1, 0, a0, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(a1, b1);
+    __builtin_amdgcn_sched_barrier(0);
   }
 
   if (EPI == 0 && P.splitk == 1) {
@@ -535,6 +627,8 @@ int launch_gemm_tn_multi(nk_ctx* ctx, const TnProblem* probs, int nprob, int64_t
     }
   }
   if (want_resid && splitk < 2) splitk = 2;  // the residual partials come out of the reduce kernel
+  if (nprob >= 3 && getenv("NYSKOOP_TN_SPLITK")) splitk = atoi(getenv("NYSKOOP_TN_SPLITK"));  // experiments
+  P.kmask = getenv("NYSKOOP_TN_KMASK") ? (int)strtol(getenv("NYSKOOP_TN_KMASK"), nullptr, 0) : -1;
   P.nprob = nprob; P.ntiles = ntiles; P.K = (int)K; P.splitk = splitk;
   P.klen = ((ktiles_total + splitk - 1) / splitk) * TBK;
   if (P.klen == 0) P.klen = TBK;
@@ -701,7 +795,7 @@ int launch_kmat_gram(nk_ctx* ctx, int ktype, const double* At, int64_t ldat, con
   dv.tile_begin = 0; dv.ktrim = KTRIM_NONE; dv.A_even = dv.B_even = nullptr; dv.Caff = nullptr; dv.aff_a = dv.aff_c = 0.0;
   dv.C = nullptr; dv.ldc = 0; dv.alpha = 1.0; dv.beta = 0.0; dv.Ct = nullptr; dv.ldct = 0;
   for (int q = 1; q < TN_MAXP; ++q) { P.p[q] = P.p[0]; P.p[q].tile_begin = 1 << 30; }
-  P.nprob = 1; P.ntiles = tmn * tnn; P.K = d; P.splitk = 1;
+  P.nprob = 1; P.ntiles = tmn * tnn; P.K = d; P.splitk = 1; P.kmask = -1;
   P.klen = ((d + TBK - 1) / TBK) * TBK;
   P.zeros = ctx->d_zeros; P.slab = nullptr;
   P.sqa = sqa; P.sqb = sqb; P.out = out; P.ldo = ldo; P.ktype = ktype; P.sigma0sq = sigma0 * sigma0;

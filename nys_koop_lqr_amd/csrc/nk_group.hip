@@ -4,6 +4,7 @@
 #include "nk_common.h"
 
 #include <algorithm>
+#include <atomic>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
@@ -73,6 +74,26 @@ struct GroupOp {
   hipMemcpyKind mk = hipMemcpyDefault;
 };
 
+// Merge key of a recorded launch: two launches share ONE merged launch only if every field is equal (the merged launch
+// takes its geometry from the first member).  The hash below only buckets; equality is exact.
+struct SigKey {
+  const void* twin = nullptr;
+  unsigned gx = 0, gy = 0, bx = 0, by = 0, bz = 0;
+  uint32_t lds = 0, psize = 0;
+  bool operator==(const SigKey& o) const {
+    return twin == o.twin && gx == o.gx && gy == o.gy && bx == o.bx && by == o.by && bz == o.bz && lds == o.lds &&
+           psize == o.psize;
+  }
+};
+struct SigHash {
+  size_t operator()(const SigKey& k) const {
+    uint64_t h = reinterpret_cast<uint64_t>(k.twin) * 0x9E3779B97F4A7C15ull;
+    auto mix = [&](uint64_t v) { h = (h ^ v) * 0xBF58476D1CE4E5B9ull; h ^= h >> 29; };
+    mix(k.gx); mix(k.gy); mix(k.bx); mix(((uint64_t)k.by << 32) | k.bz); mix(((uint64_t)k.lds << 32) | k.psize);
+    return (size_t)h;
+  }
+};
+
 struct nk_member_state {
   std::vector<GroupOp> ops;
   std::vector<char> blob;
@@ -97,6 +118,10 @@ struct nk_group {
   int live = 0;           // members not yet destroyed
   int at_align = 0;       // members parked at an alignment point
   uint64_t align_gen = 1;
+  // HIP's last error is per host thread and a merged launch is issued by whichever member arrived last, so the first
+  // failure of a flush (launch / copy return codes, hipGetLastError and the stream synchronisation, all taken in the
+  // flushing thread) is kept per epoch and handed to EVERY member that epoch releases.
+  int epoch_err = 0;  // NK_OK or NK_ERR_HIP: verdict of the last completed epoch
   // statistics
   uint64_t n_flush = 0, n_launch_merged = 0, n_launch_single = 0, n_units_merged = 0;
 };
@@ -127,19 +152,32 @@ int group_record_kernel(nk_ctx* c, const void* direct, dim3 grid, dim3 block, si
   return NK_OK;
 }
 
-static void launch_direct(nk_group* g, nk_member_state* s, const GroupOp& op) {
+static hipError_t launch_direct(nk_group* g, nk_member_state* s, const GroupOp& op) {
   void* args[64];
   char* base = s->blob.data() + op.poff;
   for (uint32_t i = 0; i < op.noff && i < 64; ++i) args[i] = base + s->offs[op.ooff + i];
-  (void)hipLaunchKernel(op.fn, op.grid, op.block, args, op.lds, g->stream);
+  return hipLaunchKernel(op.fn, op.grid, op.block, args, op.lds, g->stream);
+}
+
+// test hook (tests/test_gpu_round3.py): NYSKOOP_GROUP_TEST_FAIL_MERGED=k makes the k-th merged launch of the process
+// invalid (a block of 4096 threads), so that the error path of a flush can be exercised on a healthy device
+static bool test_fail_this_merged_launch() {
+  static const char* e = getenv("NYSKOOP_GROUP_TEST_FAIL_MERGED");
+  if (!e) return false;
+  static std::atomic<long> count{0};
+  return ++count == atol(e);
 }
 
 // Issue the recorded operations of `ready` members on the shared stream, merging equal kernel launches position by position.
 // Called with g->mu held; the caller synchronises the stream afterwards (the staging block is reused by the next flush).
-static void flush_locked(nk_group* g, const std::vector<nk_ctx*>& ready) {
+// Returns the first HIP error of the flush (hipSuccess if none).
+static hipError_t flush_locked(nk_group* g, const std::vector<nk_ctx*>& ready) {
   size_t maxlen = 0;
   for (nk_ctx* c : ready) maxlen = std::max(maxlen, st(c)->ops.size());
-  if (maxlen == 0) return;
+  if (maxlen == 0) return hipSuccess;
+  hipError_t first_err = hipSuccess;
+  auto note = [&](hipError_t e) { if (e != hipSuccess && first_err == hipSuccess) first_err = e; };
+  (void)hipGetLastError();  // errors of this thread's earlier, unrelated calls are not this flush's
   g->n_flush++;
   struct Item {
     bool merged;
@@ -151,32 +189,35 @@ static void flush_locked(nk_group* g, const std::vector<nk_ctx*>& ready) {
   // lay out argument tables and remember the order; emit = one upload, then everything in order
   auto emit = [&](bool reuse_staging) {
     const bool host_tab = getenv("NYSKOOP_GROUP_HOST_TABLE") != nullptr;
-    if (used > 0 && !host_tab) (void)hipMemcpyAsync(g->d_tab, g->h_tab, used, hipMemcpyHostToDevice, g->stream);
+    if (used > 0 && !host_tab) note(hipMemcpyAsync(g->d_tab, g->h_tab, used, hipMemcpyHostToDevice, g->stream));
     for (const Item& it : items) {
       if (it.merged) {
         const void* tab = (host_tab ? g->h_tab : g->d_tab) + it.tab_off;
         void* args[1] = {reinterpret_cast<void*>(&tab)};
         dim3 grid = it.grid;
         grid.z = (unsigned)it.count;
-        (void)hipLaunchKernel(it.twin, grid, it.block, args, it.lds, g->stream);
+        dim3 block = it.block;
+        if (test_fail_this_merged_launch()) block.x = 4096;
+        note(hipLaunchKernel(it.twin, grid, block, args, it.lds, g->stream));
         g->n_launch_merged++;
         g->n_units_merged += (uint64_t)it.count;
       } else {
         nk_member_state* s = st(it.c);
         const GroupOp& op = s->ops[it.idx];
         switch (op.kind) {
-          case OP_KERNEL: launch_direct(g, s, op); g->n_launch_single++; break;
-          case OP_MEMCPY: (void)hipMemcpyAsync(op.dst, op.src, op.bytes, op.mk, g->stream); break;
+          case OP_KERNEL: note(launch_direct(g, s, op)); g->n_launch_single++; break;
+          case OP_MEMCPY: note(hipMemcpyAsync(op.dst, op.src, op.bytes, op.mk, g->stream)); break;
           case OP_MEMCPY2D:
-            (void)hipMemcpy2DAsync(op.dst, op.dpitch, op.src, op.spitch, op.width, op.height, op.mk, g->stream);
+            note(hipMemcpy2DAsync(op.dst, op.dpitch, op.src, op.spitch, op.width, op.height, op.mk, g->stream));
             break;
-          case OP_MEMSET: (void)hipMemsetAsync(op.dst, op.value, op.bytes, g->stream); break;
+          case OP_MEMSET: note(hipMemsetAsync(op.dst, op.value, op.bytes, g->stream)); break;
         }
       }
     }
     items.clear();
+    note(hipGetLastError());
     if (reuse_staging) {
-      (void)hipStreamSynchronize(g->stream);
+      note(hipStreamSynchronize(g->stream));
       used = 0;
     }
   };
@@ -188,12 +229,13 @@ static void flush_locked(nk_group* g, const std::vector<nk_ctx*>& ready) {
   // extra iteration) instead of letting one shift break every later merge.
   const size_t R = ready.size();
   std::vector<size_t> cur(R, 0);
-  auto sig_of = [](const GroupOp& o) -> uint64_t {
-    uint64_t h = reinterpret_cast<uint64_t>(o.twin) * 0x9E3779B97F4A7C15ull;
-    h ^= ((uint64_t)o.grid.x << 32) ^ ((uint64_t)o.grid.y << 20) ^ ((uint64_t)o.block.x << 8) ^ o.lds ^ ((uint64_t)o.psize << 44);
-    return h;
+  auto sig_of = [](const GroupOp& o) -> SigKey {  // (grid.z == 1 for every launch that has a twin, group_record_kernel)
+    SigKey k;
+    k.twin = o.twin; k.gx = o.grid.x; k.gy = o.grid.y; k.bx = o.block.x; k.by = o.block.y; k.bz = o.block.z;
+    k.lds = o.lds; k.psize = o.psize;
+    return k;
   };
-  std::vector<std::unordered_map<uint64_t, int>> remaining(R);  // mergeable signatures at or after the cursor, with counts
+  std::vector<std::unordered_map<SigKey, int, SigHash>> remaining(R);  // mergeable signatures at or after the cursor, with counts
   for (size_t a = 0; a < R; ++a)
     for (const GroupOp& o : st(ready[a])->ops)
       if (o.kind == OP_KERNEL && o.twin) remaining[a][sig_of(o)]++;
@@ -211,12 +253,12 @@ static void flush_locked(nk_group* g, const std::vector<nk_ctx*>& ready) {
     }
     if (!any) break;
     // 2. choose a signature among the launches at the cursors
-    std::unordered_map<uint64_t, int> holders;
+    std::unordered_map<SigKey, int, SigHash> holders;
     for (size_t a = 0; a < R; ++a) {
       nk_member_state* sa = st(ready[a]);
       if (cur[a] < sa->ops.size()) holders[sig_of(sa->ops[cur[a]])]++;
     }
-    uint64_t best = 0, best_any = 0;
+    SigKey best, best_any;
     int best_n = -1, best_any_n = -1;
     if (holders.size() == 1) {  // the common case: everybody is at the same launch
       best = holders.begin()->first;
@@ -233,7 +275,7 @@ static void flush_locked(nk_group* g, const std::vector<nk_ctx*>& ready) {
       if (kv.second > best_any_n) { best_any_n = kv.second; best_any = kv.first; }
       if (!ahead_elsewhere && kv.second > best_n) { best_n = kv.second; best = kv.first; }
     }
-    const uint64_t pick = best_n > 0 ? best : best_any;
+    const SigKey pick = best_n > 0 ? best : best_any;
     grp.clear();
     for (size_t a = 0; a < R; ++a) {
       nk_member_state* sa = st(ready[a]);
@@ -265,35 +307,55 @@ static void flush_locked(nk_group* g, const std::vector<nk_ctx*>& ready) {
     s->blob.clear();
     s->offs.clear();
   }
+  return first_err;
+}
+
+// flush + real synchronisation of the shared stream; NK_OK or NK_ERR_HIP (message in the calling thread's error slot)
+static int flush_and_sync_locked(nk_group* g, const std::vector<nk_ctx*>& ready) {
+  hipError_t e = flush_locked(g, ready);
+  const hipError_t es = hipStreamSynchronize(g->stream);
+  if (e == hipSuccess) e = es;
+  if (e == hipSuccess) return NK_OK;
+  set_error("lock-step group: a merged flush failed (%s); every member of the round gets this error", hipGetErrorString(e));
+  return NK_ERR_HIP;
+}
+// release the members that were waiting for the flush just done (g->mu held): they all see its verdict
+static void release_waiters_locked(nk_group* g, const std::vector<nk_ctx*>& ready, int verdict) {
+  for (nk_ctx* m : ready) st(m)->waiting = false;
+  g->waiting = 0;
+  g->epoch_err = verdict;
+  g->epoch++;
+}
+static std::vector<nk_ctx*> waiting_members(nk_group* g) {
+  std::vector<nk_ctx*> ready;
+  for (nk_ctx* m : g->members)
+    if (m && st(m)->waiting) ready.push_back(m);
+  return ready;
 }
 
 int group_sync(nk_ctx* c) {
   nk_group* g = c->group;
   nk_member_state* s = st(c);
   std::unique_lock<std::mutex> lk(g->mu);
-  if (!s->entered) {  // outside a unit of work: nobody to wait for
-    flush_locked(g, std::vector<nk_ctx*>{c});
-    hipError_t e = hipStreamSynchronize(g->stream);
-    return e == hipSuccess ? NK_OK : NK_ERR_HIP;
-  }
+  if (!s->entered)  // outside a unit of work: nobody to wait for
+    return flush_and_sync_locked(g, std::vector<nk_ctx*>{c});
   s->waiting = true;
   g->waiting++;
   if (g->waiting >= g->active) {
-    std::vector<nk_ctx*> ready;
-    for (nk_ctx* m : g->members)
-      if (m && st(m)->waiting) ready.push_back(m);
-    flush_locked(g, ready);
-    hipError_t e = hipStreamSynchronize(g->stream);
-    for (nk_ctx* m : ready) st(m)->waiting = false;
-    g->waiting = 0;
-    g->epoch++;
+    const std::vector<nk_ctx*> ready = waiting_members(g);
+    const int rc = flush_and_sync_locked(g, ready);
+    release_waiters_locked(g, ready, rc);
     lk.unlock();
     g->cv.notify_all();
-    return e == hipSuccess ? NK_OK : NK_ERR_HIP;
+    return rc;
   }
   const uint64_t ep = g->epoch;
   g->cv.wait(lk, [&] { return g->epoch != ep; });
-  return NK_OK;
+  // (the next epoch cannot complete before this member arrives again, so epoch_err still belongs to the epoch that
+  // released it)
+  const int rc = g->epoch_err;
+  if (rc != NK_OK) set_error("lock-step group: the merged flush of this round failed in another member's thread");
+  return rc;
 }
 
 // Alignment point: a member that leaves a data-dependent region (an iteration whose length differs from unit to unit)
@@ -406,7 +468,11 @@ void group_attach(nk_group* g, int slot, nk_ctx* c) {
   c->group = g;
   c->gstate = new nk_member_state();
 }
+static std::atomic<uint64_t> g_counters[CNT_N];
+void count_event(int which) { if (which >= 0 && which < CNT_N) g_counters[which].fetch_add(1, std::memory_order_relaxed); }
+uint64_t read_counter(int which) { return g_counters[which].load(std::memory_order_relaxed); }
 hipError_t real_stream_sync(hipStream_t s) { return hipStreamSynchronize(s); }
+hipError_t real_event_sync(hipEvent_t e) { return hipEventSynchronize(e); }
 hipStream_t group_stream(nk_group* g) { return g->stream; }
 // member going away: flush what it recorded, leave the barrier set, free the group with its last member
 void group_detach(nk_ctx* c) {
@@ -416,22 +482,15 @@ void group_detach(nk_ctx* c) {
   {
     std::unique_lock<std::mutex> lk(g->mu);
     nk_member_state* s = st(c);
-    if (!s->ops.empty()) {
-      flush_locked(g, std::vector<nk_ctx*>{c});
-      (void)hipStreamSynchronize(g->stream);
-    }
+    if (!s->ops.empty()) (void)flush_and_sync_locked(g, std::vector<nk_ctx*>{c});  // a context being destroyed: nobody to tell
     if (s->entered) { s->entered = false; g->active--; }
     for (auto& m : g->members) if (m == c) m = nullptr;
     last = --g->live == 0;
     // members still waiting may now be complete
     if (!last && g->active > 0 && g->waiting >= g->active) {
-      std::vector<nk_ctx*> ready;
-      for (nk_ctx* m : g->members) if (m && st(m)->waiting) ready.push_back(m);
-      flush_locked(g, ready);
-      (void)hipStreamSynchronize(g->stream);
-      for (nk_ctx* m : ready) st(m)->waiting = false;
-      g->waiting = 0;
-      g->epoch++;
+      const std::vector<nk_ctx*> ready = waiting_members(g);
+      const int rc = flush_and_sync_locked(g, ready);
+      release_waiters_locked(g, ready, rc);
       g->cv.notify_all();
     }
   }
@@ -459,10 +518,9 @@ int group_leave(nk_ctx* c) {
   std::unique_lock<std::mutex> lk(g->mu);
   nk_member_state* s = st(c);
   if (!s->entered) return NK_OK;
-  if (!s->ops.empty()) {  // work recorded after the last synchronisation point
-    flush_locked(g, std::vector<nk_ctx*>{c});
-    (void)hipStreamSynchronize(g->stream);
-  }
+  int rc_own = NK_OK;
+  if (!s->ops.empty())  // work recorded after the last synchronisation point
+    rc_own = flush_and_sync_locked(g, std::vector<nk_ctx*>{c});
   s->entered = false;
   g->active--;
   if (g->active > 0 && g->at_align >= g->active) {  // the others were parked at an alignment point waiting for this member
@@ -470,17 +528,13 @@ int group_leave(nk_ctx* c) {
     g->align_gen++;
   }
   if (g->active > 0 && g->waiting >= g->active) {  // the others were only waiting for this member
-    std::vector<nk_ctx*> ready;
-    for (nk_ctx* m : g->members) if (m && st(m)->waiting) ready.push_back(m);
-    flush_locked(g, ready);
-    (void)hipStreamSynchronize(g->stream);
-    for (nk_ctx* m : ready) st(m)->waiting = false;
-    g->waiting = 0;
-    g->epoch++;
+    const std::vector<nk_ctx*> ready = waiting_members(g);
+    const int rc = flush_and_sync_locked(g, ready);
+    release_waiters_locked(g, ready, rc);
     lk.unlock();
     g->cv.notify_all();
   }
-  return NK_OK;
+  return rc_own;
 }
 void group_stats(nk_ctx* c, uint64_t out[4]) {
   nk_group* g = c->group;

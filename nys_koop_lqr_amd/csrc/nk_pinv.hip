@@ -648,6 +648,7 @@ int pinv_right_divide(nk_ctx* ctx, const double* P, int64_t ldp, int m, const do
         // a workgroup gave up waiting for the others (they were not all resident): finish with one launch per round
         ctx->h_info[9] = 0;
         one_launch = false;
+        count_event(CNT_JACOBI_GIVEUP);
         if (trace) fprintf(stderr, "[nk pinv] single-launch sweep gave up waiting: one launch per round from here\n");
         continue;
       }

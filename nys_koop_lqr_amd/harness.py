@@ -234,6 +234,18 @@ def lqr_control_plant(num_steps, reference, initial_state, regressor, K, plant_s
     return np.array(xs), np.hstack(us)
 
 
+def open_loop_control(plant_step, initial_state, controls):
+    """benchmark_lqr_classic.py:91-97: replay a control sequence (p x T) on the true plant; returns the visited states
+    (d x (T + 1)), the initial state first."""
+    state = np.asarray(initial_state, dtype=np.float64).reshape(-1, 1)
+    controls = np.asarray(controls, dtype=np.float64)
+    states = [state]
+    for i in range(controls.shape[1]):
+        state = np.asarray(plant_step(state, controls[:, i].reshape(-1, 1)), dtype=np.float64).reshape(-1, 1)
+        states.append(state)
+    return np.hstack(states)
+
+
 def control_rmse_percent(us, u_opt):
     """benchmark_lqr_hjb.py:313 / :378."""
     us, u_opt = np.asarray(us).squeeze(), np.asarray(u_opt).squeeze()

@@ -232,7 +232,11 @@ def rollout(A, B, C, z0, controls):
 def validate_dyn_sys(reg, true_trajectory, test_controls, relative=False):
     """benchmark_lqr_cloth.py:18-36 (absolute RMSE, :34) / benchmark_lqr_classic.py:23-41 (relative-%, :39)."""
     z0 = reg.lift(true_trajectory[:, 0].reshape(-1, 1))
-    sim, _ = rollout(reg.A, reg.B, reg.C, z0, test_controls[:, : true_trajectory.shape[1]])
+    T = true_trajectory.shape[1]
+    ctrl = test_controls[:, :T]
+    if ctrl.shape[1] == T - 1:  # classic / hjb drivers: one control per transition (the loop of :33 uses all of them)
+        ctrl = np.hstack((ctrl, np.zeros((ctrl.shape[0], 1))))  # rollout() ignores the last column
+    sim, _ = rollout(reg.A, reg.B, reg.C, z0, ctrl)
     if relative:
         return np.sqrt(np.sum(np.square(true_trajectory - sim))) / np.sqrt(np.sum(np.square(sim))) * 100
     return np.sqrt(np.mean(np.square(true_trajectory - sim)))

@@ -278,3 +278,101 @@ def test_c5_full_size_properties(nk):
     ne = relf(lhs, rhs)
     print(f"[C5 full size] additivity {add_err:.1e}, normal-equation residual {ne:.1e}")
     assert ne < 1e-6
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# config 1 at the reference driver's real shape: benchmark_lqr_classic.py:174-179,211-299 on duffing/*.csv (n = 69 900)
+# ---------------------------------------------------------------------------------------------------------------
+def _duffing_fit(nk, g, idx, m):
+    reg = nk.KoopmanNystromRegressor(1, kernel=nk.KernelWrapper([1, 1]), gamma=float(g["gamma"]), m=int(m))
+    reg.nystrom_centers_output = np.ascontiguousarray(g["Y"].T[:, idx])
+    reg.fit(g["X"], g["Y"])
+    return reg
+
+
+def test_duffing_full_shape_open_loop_sweep_vs_reference(nk, golden):
+    """The open-loop validation sweep of benchmark_lqr_classic.py:211-255 at its real shape -- n = 69 900 samples, Matern-5/2,
+    m = around(logspace(1, 2.3, 20)), seeds 0..2: 60 fits on the HIP path with the landmarks the reference drew, each
+    followed by the 100-step forecast and the relative-% RMSE of :39.
+
+    Bar, fit by fit, from two reference-side numbers (tests/golden/make_golden_envelope.py): `spread` -- how far the
+    reference's own RMSE moves when its inputs are perturbed by one part in 1e15 -- and `envelope` -- how far it moves when
+    the SAME reference code calls another LAPACK driver for its two solves (gelsy, Cholesky, truncated symmetric
+    eigen-solve).  For m >= 57 (cond(inner) ~ 1e13..1e14) gelsd is the odd one out: the three other drivers agree with
+    each other to 1e-4 and sit 5e-5..2e-2 from gelsd, which is itself reproducible to 1e-6..3e-4 -- a systematic error of
+    its divide-and-conquer SVD (absolute, not relative, accuracy of sigma_min ~ 1e-14 sigma_max), not noise.  No solver can
+    be closer to the reference than LAPACK's own drivers are: bar = max(10 spread, 1.5 envelope, 1e-8).  Below m = 57 the
+    envelope is within the spread and the bar is the reference's reproducibility alone.  The first column (m = 10) is
+    also held against the file the AUTHORS shipped (duffing/all_rmses_nystrom_double_dataset.csv, seeds 0..7)."""
+    from nys_koop_lqr_amd import harness
+    g = golden("f12_duffing_full.npz")
+    ms = g["ms"]
+    K_BAR, K_ENV, FLOOR = 10.0, 1.5, 1e-8
+    ref, refp = g["ref_rmse"], g["ref_rmse_perturbed"]
+    spread = np.abs(refp - ref) / ref
+    envelope = golden("f12b_duffing_envelope.npz")["envelope"]
+    rows = []
+    worst = 0.0
+    t0 = time.time()
+    for si, seed in enumerate(g["seeds"]):
+        traj, ctrl = g[f"traj_{seed}"], g[f"ctrl_{seed}"]
+        for k, m in enumerate(ms):
+            reg = _duffing_fit(nk, g, g[f"idx_{seed}_{k}"], m)
+            rmse = harness.validate_dyn_sys(reg, traj, ctrl, relative=True)
+            err = abs(rmse - ref[si, k]) / ref[si, k]
+            bar = max(K_BAR * spread[si, k], K_ENV * envelope[si, k], FLOOR)
+            rows.append((int(seed), int(m), ref[si, k], rmse, err, spread[si, k], envelope[si, k], err / bar))
+            worst = max(worst, err / bar)
+    dt = time.time() - t0
+    print(f"\nduffing full shape: 60 fits + forecasts at n = 69900 in {dt:.2f} s; worst err / bar = {worst:.3f}")
+    print("seed    m   ref_rmse%      gpu_rmse%     rel.err   ref.spread   envelope  err/bar")
+    for r in rows:
+        print("%4d %4d %12.6f %12.6f %10.2e %10.2e %10.2e %8.3f" % r)
+    assert worst <= 1.0, [r for r in rows if r[-1] > 1.0]
+    # the authors' own numbers: first column of the shipped file, seeds 0..7
+    first = []
+    for seed in range(8):
+        reg = _duffing_fit(nk, g, g[f"idx_{seed}_0"], 10)
+        first.append(harness.validate_dyn_sys(reg, g[f"traj_{seed}"], g[f"ctrl_{seed}"], relative=True))
+    dev = np.abs(np.array(first) - g["shipped_first_col"]) / g["shipped_first_col"]
+    print("first column vs the shipped all_rmses_nystrom_double_dataset.csv, seeds 0..7:", dev)
+    assert dev.max() < 1e-5, dev
+
+
+@pytest.mark.parametrize("m", [10, 48, 200])
+def test_duffing_full_shape_operators_vs_reference(nk, golden, m):
+    """Operators of (seed 0, m) at n = 69 900 against the reference's; bar = 10 x the movement of the reference's own
+    operators under the 1e-15 input perturbation (floor 1e-9)."""
+    g = golden("f12_duffing_full.npz")
+    k = int(np.where(g["ms"] == m)[0][0])
+    reg = _duffing_fit(nk, g, g[f"idx_0_{k}"], m)
+    bar = max(10.0 * float(g["op_sensitivity"][0, k]), 1e-9)
+    errs = dict(A=relf(reg.A, g[f"A_m{m}"]), B=relf(reg.B, g[f"B_m{m}"]), C=relf(reg.C, g[f"C_m{m}"]))
+    print(f"\nduffing n=69900 m={m}: {errs}, bar {bar:.2e} (reference moves {float(g['op_sensitivity'][0, k]):.2e})")
+    assert max(errs.values()) <= bar, (errs, bar)
+
+
+def test_duffing_plant_in_the_loop_lqr_vs_reference(nk, O, golden):
+    """benchmark_lqr_classic.py:256-299: m = 20 fit on the full data set, K = dlqr(A, B, C^T C, I), 2000 steps of u = K (phi(0)
+    - phi(x)) with the PLANT in the loop (a lift per step) and the open-loop replay of the controls (:91-97), seeds 0..2,
+    against the reference's own run (plant = the oracle's restatement of dynamical_systems.py:25-48; test infrastructure).
+    The loop feeds its own state back 2000 times, so the bar is on the trajectory as a whole."""
+    from nys_koop_lqr_amd import harness
+    from nys_koop_lqr_amd.lqr import dlqr
+    g = golden("f12_duffing_full.npz")
+    steps = int(g["lqr_steps"])
+    plant = lambda x, u: O.duffing_step(x, u, 0.01)
+    x0, ref0 = np.array([[-0.5], [0.0]]), np.zeros((2, 1))
+    for seed in g["seeds"]:
+        reg = _duffing_fit(nk, g, g[f"lqr_idx_{seed}"], 20)
+        e_ops = max(relf(reg.A, g[f"lqr_A_{seed}"]), relf(reg.B, g[f"lqr_B_{seed}"]), relf(reg.C, g[f"lqr_C_{seed}"]))
+        K, _ = dlqr(reg.A, reg.B, reg.C.T @ reg.C, np.eye(1))
+        e_K = relf(K, g[f"lqr_K_{seed}"])
+        t0 = time.time()
+        _, us = harness.lqr_control_plant(steps, ref0, x0, reg, K, plant)
+        dt = time.time() - t0
+        states = harness.open_loop_control(plant, x0, us)
+        e_u, e_x = relf(us, g[f"lqr_us_{seed}"]), relf(states, g[f"lqr_states_{seed}"])
+        print(f"\nduffing LQR seed {seed}: operators {e_ops:.2e}, K {e_K:.2e}, controls {e_u:.2e}, states {e_x:.2e} "
+              f"({steps} plant-in-the-loop steps in {dt:.2f} s)")
+        assert e_ops < 1e-6 and e_K < 1e-5 and e_u < 1e-4 and e_x < 1e-4

@@ -1,0 +1,90 @@
+"""GPU tests added in round 3: error propagation out of a merged lock-step flush, the slow-path counters, and the
+software-pipelined TN engine (results against NumPy on shapes that hit every tile class)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import relf
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def nk():
+    import nys_koop_lqr_amd as nk
+    nk.get_context()
+    return nk
+
+
+def test_failed_merged_launch_reaches_every_unit_of_the_round():
+    """A merged launch is issued by whichever member thread arrives last; HIP's last error is per host thread.  The first
+    error of a flush must reach EVERY member the flush releases: with the 40th merged launch of the process made invalid
+    (block of 4096 threads), all units of that round report a non-zero status and a NaN score -- none reports success
+    on buffers the device never wrote -- and a later sweep in the same process is clean again."""
+    code = r'''
+import numpy as np, sys
+sys.path.insert(0, %r)
+import nys_koop_lqr_amd as nk
+from nys_koop_lqr_amd import _lib
+rng = np.random.default_rng(3)
+n, d, p, m = 505, 24, 2, 64
+S = rng.standard_normal((n, d)); U = rng.standard_normal((n, p))
+Y = np.tanh(S @ (rng.standard_normal((d, d)) * 0.8 / np.sqrt(d))) + U @ (rng.standard_normal((p, d)) * 0.1)
+X = np.hstack([S, U])
+kern = nk.ThreeDimensionalKernel(4., 4., 4., d).kernel
+folds = [(0, 101), (101, 202), (202, 303), (303, 404), (404, 505)]
+units = []
+for u in range(8):
+    lo, hi = folds[u %% 5]
+    idx = np.random.RandomState(u).choice(n - 101, m, replace=False)
+    units.append((kern, 1e-4, 1e-6, m, (lo, hi), np.where(idx < lo, idx, idx + (hi - lo))))
+pool = _lib.lockstep_pool(8)
+sc, st = pool.cv_grid(X, Y, p, units)
+print("ROUND1", int(np.count_nonzero(st)), int(np.count_nonzero(np.isfinite(sc))))
+sc2, st2 = pool.cv_grid(X, Y, p, units)
+print("ROUND2", int(np.count_nonzero(st2)), int(np.count_nonzero(np.isfinite(sc2))))
+''' % ROOT
+    env = dict(os.environ, NYSKOOP_GROUP_TEST_FAIL_MERGED="40")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, (out.returncode, out.stdout[-500:], out.stderr[-2000:])
+    lines = dict(l.split(" ", 1) for l in out.stdout.splitlines() if l.startswith("ROUND"))
+    bad1, finite1 = (int(v) for v in lines["ROUND1"].split())
+    assert bad1 == 8 and finite1 == 0, lines    # every unit of the failing round saw the error
+    bad2, finite2 = (int(v) for v in lines["ROUND2"].split())
+    assert bad2 == 0 and finite2 == 8, lines    # and the group is usable afterwards
+
+
+def test_runtime_counters_count_the_rank_truncating_branch(nk):
+    from nys_koop_lqr_amd import _lib
+    before = _lib.runtime_counters()
+    rng = np.random.default_rng(5)
+    n, d, p, m = 300, 6, 1, 24
+    S = rng.standard_normal((n, d)); U = rng.standard_normal((n, p))
+    Y = np.tanh(S) + 0.1 * U
+    X = np.hstack([S, U])
+    reg = nk.KoopmanNystromRegressor(p, kernel=nk.ThreeDimensionalKernel(2., 2., 2., d), gamma=1e-14, m=m)
+    idx = np.concatenate([np.arange(16), np.arange(8)])  # duplicated landmarks: an exact null space
+    reg.nystrom_centers_output = Y.T[:, idx]
+    reg.fit(X, Y)
+    after = _lib.runtime_counters()
+    assert after["rank_truncated_fits"] == before["rank_truncated_fits"] + 1
+    assert set(after) == {"chain_giveups", "jacobi_giveups", "rank_truncated_fits", "sqrt_retries"}
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (2006, 2000, 1000), (384, 2000, 777), (130, 258, 17), (2, 2, 3),
+                                   (640, 640, 5000)])
+def test_tn_engine_products_vs_numpy(nk, M, N, K):
+    """C = A^T B through nk_gemm (the LDS-DMA / MFMA engine with the software-pipelined operand fetch): full tiles, edge
+    tiles in both directions, K tails that are not multiples of the 16-row step, a K range shorter than one step."""
+    from nys_koop_lqr_amd import _lib
+    rng = np.random.default_rng(M + 7 * N + 13 * K)
+    A = rng.standard_normal((K, M)); B = rng.standard_normal((K, N))
+    ctx = nk.get_context()
+    C = np.empty((M, N))
+    _lib.check(ctx.lib.nk_gemm(ctx.handle, 1, 0, M, N, K, 1.0, A.ctypes.data, M, B.ctypes.data, N, 0.0, C.ctypes.data, N))
+    ref = A.T @ B
+    assert relf(C, ref) < 5e-15

@@ -122,3 +122,34 @@ def test_every_environment_switch_is_documented():
     doc = open(os.path.join(root, "INTEGRATION.md")).read()
     missing = sorted(n for n in names if n not in doc and n not in ("NYSKOOP_BENCH_BACKEND",))
     assert not missing, f"undocumented environment switches: {missing}"
+
+
+def test_no_raw_hip_stream_call_escapes_the_lockstep_wrappers():
+    """nk_lockstep.h redefines hipLaunchKernelGGL / hipMemcpyAsync / hipStreamSynchronize / ... by macro so that a member of
+    a lock-step group records instead of issuing.  Spellings the macros do not catch (<<< >>>, hipLaunchKernel, the
+    blocking hipMemcpy / hipMemset family, hipDeviceSynchronize, graph or cooperative launches) would silently escape
+    the recording: the only ones allowed are listed here with the reason they are safe."""
+    allowed = {
+        # nk_cv_grid stages X / Y once, before any member thread exists (blocking copies on the caller's thread)
+        ("nk_api.hip", "hipMemcpy2D("): 3,
+        # one-time zero page of a context, blocking on purpose (both streams read it)
+        ("nk_gemm_tn.hip", "hipMemset("): 1,
+    }
+    pat = re.compile(r"<<<|\bhipLaunchKernel\(|\bhipMemcpy\(|\bhipMemcpy2D\(|\bhipMemset\(|\bhipDeviceSynchronize\(|"
+                     r"\bhipModuleLaunchKernel\(|\bhipLaunchCooperativeKernel\(|\bhipGraphLaunch\(|\bhipMemcpyDtoH\(|"
+                     r"\bhipMemcpyHtoD\(|\bhipMemsetD8\(")
+    csrc = os.path.join(ROOT, "nys_koop_lqr_amd", "csrc")
+    seen = {}
+    for f in sorted(os.listdir(csrc)):
+        if not f.endswith((".hip", ".h")) or f in ("nk_group.hip", "nk_lockstep.h"):
+            continue  # the two files that implement the wrappers call the real functions
+        for line in open(os.path.join(csrc, f)):
+            code = line.split("//")[0]
+            for mt in pat.finditer(code):
+                seen[(f, mt.group(0))] = seen.get((f, mt.group(0)), 0) + 1
+    assert seen == allowed, f"raw HIP calls outside the lock-step wrappers: {seen} (allowed: {allowed})"
+    # and every translation unit with device code sees the macros
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith(".hip") and f != "nk_group.hip":
+            assert '#include "nk_common.h"' in open(os.path.join(csrc, f)).read(), f
+    assert '#include "nk_lockstep.h"' in open(os.path.join(csrc, "nk_common.h")).read()

@@ -181,3 +181,22 @@ def test_truncated_solve_is_gelsd_where_gelsd_is_stable(golden):
     if rk == rko == 30:
         assert relf(Xo, Xg) < 1e-6
     assert relf(O.truncated_solve(P, R, rcond=1e-10)[0], O.truncated_solve(P, R, rcond=1e-12)[0]) < 1e-9
+
+
+@pytest.mark.parametrize("m", [10, 48])
+def test_oracle_vs_reference_duffing_full_shape(golden, m):
+    """Config 1 at the driver's real shape (benchmark_lqr_classic.py:174-179,211-255; n = 69 900, Matern-5/2, gamma = 1e-6):
+    the faithful oracle against the reference's operators and relative-% RMSE (f12, seed 0), and -- for m = 10 -- against
+    the first column of the file the authors shipped."""
+    from oracle import nk_oracle as O
+    g = golden("f12_duffing_full.npz")
+    k = int(np.where(g["ms"] == m)[0][0])
+    reg = O.KoopmanNystromOracle(1, kernel=O.KernelWrapper([1, 1]), gamma=float(g["gamma"]), m=m)
+    reg.nystrom_centers_output = g["Y"].T[:, g[f"idx_0_{k}"]]
+    reg.fit(g["X"], g["Y"])
+    bar = max(10 * float(g["op_sensitivity"][0, k]), 1e-9)
+    assert max(relf(reg.A, g[f"A_m{m}"]), relf(reg.B, g[f"B_m{m}"]), relf(reg.C, g[f"C_m{m}"])) < bar
+    rmse = O.validate_dyn_sys(reg, g["traj_0"], g["ctrl_0"], relative=True)
+    assert abs(rmse - g["ref_rmse"][0, k]) / g["ref_rmse"][0, k] < max(10 * abs(g["ref_rmse_perturbed"][0, k] - g["ref_rmse"][0, k]) / g["ref_rmse"][0, k], 1e-8)
+    if m == 10:
+        assert abs(rmse - g["shipped_first_col"][0]) / g["shipped_first_col"][0] < 1e-6
