@@ -100,6 +100,16 @@ int nk_set_kmat_mode(nk_ctx* ctx, int mode);
  * agree on it -- DESIGN.md section 3.)  strict = 1 turns the fallback into NK_ERR_NOT_SPD (also: environment variable
  * NYSKOOP_STRICT_SPD=1 before nk_create). */
 int nk_set_strict_spd(nk_ctx* ctx, int strict);
+/* Arithmetic of the two O(n m d) kernel blocks and the O(n m^2) Gram contractions of nk_nystrom_fit / nk_nystrom_gram
+ * (regressors.py:141-142,151,153,162,164).  NK_DTYPE_F64 (default): fp64 end to end, the only mode that meets the 1e-6
+ * operator bar.  NK_DTYPE_F32 (the stress configuration of BASELINE.json: n = 1e6, m = 8000, d = 1024, "fp32"): rows and
+ * kernel values are rounded to fp32 and multiplied on the fp32 matrix pipe (twice the fp64 rate, half the bytes); the
+ * Gram accumulators are kept in fp64 (fp32 partial sums never run over more than 1024 rows) and everything m x m --
+ * regularised solves, square root, operators, lift, predict, rollouts -- stays fp64.  Needs d >= 32 and shared input /
+ * output landmarks; contexts of a lock-step group ignore it. */
+#define NK_DTYPE_F64 0
+#define NK_DTYPE_F32 1
+int nk_set_compute_dtype(nk_ctx* ctx, int dtype);
 /* Stream ordering for DEVICE-pointer arguments: work already queued on `producer_stream` (a hipStream_t; NULL = the
  * legacy default stream) is ordered before everything this context launches afterwards -- an event recorded on the
  * producer stream that all of the context's streams wait for; the host does not block.  Call it before handing the
@@ -266,6 +276,11 @@ int nk_linear_rollout(nk_ctx* ctx, const double* A, const double* B, const doubl
 
 /* ---- building blocks exported for parity tests and reuse (device or host pointers) --------------------- */
 /* C[M x N] = alpha * op(A) op(B) + beta * C;  transA: A is stored K x M;  transB: B is stored N x K. */
+/* C[M x N] (fp64) = A^T B with fp32 operands stored K x M / K x N (the fp32 engine of nk_set_compute_dtype as a building
+ * block: fp32 products, fp32 partial sums over at most 1024 rows, fp64 beyond).  Operands 16-byte aligned, lda / ldb
+ * multiples of 4, M, N >= 4. */
+int nk_gemm_f32(nk_ctx* ctx, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,
+                double* C, int64_t ldc);
 int nk_gemm(nk_ctx* ctx, int transA, int transB, int64_t M, int64_t N, int64_t K, double alpha,
             const double* A, int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc);
 /* S = P^{1/2}, Sinv = P^{-1/2} for symmetric positive definite P (m x m); regressors.py:140,163,175. */

@@ -64,6 +64,7 @@ SIGNATURES = {
     "nk_group_create": (C.c_int, [C.c_int, C.c_int, C.POINTER(_P)]),
     "nk_group_enter": (C.c_int, [_P]),
     "nk_group_leave": (C.c_int, [_P]),
+    "nk_set_compute_dtype": (C.c_int, [_P, C.c_int]),
     "nk_group_stats": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
     "nk_runtime_counters": (C.c_int, [C.POINTER(C.c_uint64), C.c_int32]),
     "nk_cv_grid": (C.c_int, [C.POINTER(_P), _I32, _P, _I64, _P, _I64, _I64, _I32, _I32, C.POINTER(CvUnit), _I32,
@@ -94,6 +95,7 @@ SIGNATURES = {
     "nk_closed_loop": (C.c_int, [_P, _P, _P, _P, _P, _I32, _P, _P]),
     "nk_closed_loop_batch": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _P, _P]),
     "nk_linear_rollout": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _P, _P, _I32, _I32, _P, _P]),
+    "nk_gemm_f32": (C.c_int, [_P, _I64, _I64, _I64, _P, _I64, _P, _I64, _P, _I64]),
     "nk_gemm": (C.c_int, [_P, C.c_int, C.c_int, _I64, _I64, _I64, _D, _P, _I64, _P, _I64, _D, _P, _I64]),
     "nk_sqrtm_spd": (C.c_int, [_P, _P, _I64, _I32, _P, _P, C.POINTER(_I32), C.POINTER(_D)]),
     "nk_solve_spd": (C.c_int, [_P, _P, _I64, _I32, _P, _I64, _I32, _P, _I64]),
@@ -269,6 +271,14 @@ class Context:
                 stream = torch.cuda.current_stream(o.device)
                 check(self.lib.nk_wait_stream(self.handle, C.c_void_p(stream.cuda_stream)))
                 return
+
+    def set_compute_dtype(self, dtype):
+        """'f64' (default) or 'f32': arithmetic of the kernel blocks and Gram contractions of fits on this context
+        (nk_set_compute_dtype: the stress configuration's fp32 engine; everything m x m stays fp64)."""
+        code = {"f64": 0, "f32": 1}.get(str(dtype))
+        if code is None:
+            raise ValueError("dtype must be 'f64' or 'f32'")
+        check(self.lib.nk_set_compute_dtype(self.handle, code))
 
     def set_kmat_mode(self, mode):
         """0 = automatic (Gram form on the MFMA engine for d >= 32), 1 = always direct differences."""

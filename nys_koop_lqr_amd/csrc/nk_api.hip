@@ -402,6 +402,10 @@ int nk_create(int device, nk_ctx** out) {
   NK_HIP(hipStreamCreateWithPriority(&ctx->stream_side, hipStreamNonBlocking, prio_lo));
   NK_HIP(hipStreamCreateWithPriority(&ctx->stream_prep, hipStreamNonBlocking, prio_hi));
   NK_HIP(hipStreamCreateWithFlags(&ctx->stream_copy, hipStreamNonBlocking));
+  NK_HIP(hipStreamCreateWithPriority(&ctx->stream_la[0], hipStreamNonBlocking, prio_hi));
+  NK_HIP(hipStreamCreateWithPriority(&ctx->stream_la[1], hipStreamNonBlocking, prio_mid));
+  for (int q = 0; q < 2; ++q)
+    for (int i = 0; i < 4; ++i) NK_HIP(hipEventCreateWithFlags(&ctx->ev_la[q][i], hipEventDisableTiming));
   ctx->stream = ctx->stream_main;
   ctx->cur_arena = &ctx->arena;
   NK_HIP(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
@@ -435,6 +439,10 @@ static void destroy_ctx_unregistered(nk_ctx* ctx) {
   (void)hipStreamSynchronize(ctx->stream_side);
   (void)hipStreamSynchronize(ctx->stream_prep);
   (void)hipStreamSynchronize(ctx->stream_copy);
+  for (int q = 0; q < 2; ++q) {
+    if (ctx->stream_la[q]) { (void)hipStreamSynchronize(ctx->stream_la[q]); (void)hipStreamDestroy(ctx->stream_la[q]); }
+    for (int i = 0; i < 4; ++i) if (ctx->ev_la[q][i]) (void)hipEventDestroy(ctx->ev_la[q][i]);
+  }
   for (auto& c : ctx->arena.chunks) (void)hipFree(c.base);
   for (auto& c : ctx->arena_side.chunks) (void)hipFree(c.base);
   (void)hipEventDestroy(ctx->ev_fork);
@@ -499,6 +507,12 @@ int nk_shutdown(void) {
   for (nk_ctx* c : ctxs) destroy_ctx_unregistered(c);
   pool_drain();
   for (void* b : blocks) (void)hipHostFree(b);
+  return NK_OK;
+}
+
+int nk_set_compute_dtype(nk_ctx* ctx, int dtype) {
+  NK_REQUIRE(ctx != nullptr && (dtype == NK_DTYPE_F64 || dtype == NK_DTYPE_F32), "nk_set_compute_dtype: bad argument");
+  ctx->compute_f32 = dtype == NK_DTYPE_F32 ? 1 : 0;
   return NK_OK;
 }
 
@@ -821,6 +835,8 @@ static int fit_impl(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int6
         (void)hipStreamSynchronize(c->stream_main);
         (void)hipStreamSynchronize(c->stream_side);
         (void)hipStreamSynchronize(c->stream_prep);
+        (void)hipStreamSynchronize(c->stream_la[0]);
+        (void)hipStreamSynchronize(c->stream_la[1]);
         nk_model_destroy(m);
       }
     }
@@ -921,13 +937,17 @@ static int fit_impl(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int6
   // ---- feature matrix F = [K_nm_in | U | (pad) | K_nm_out], sample-major (regressors.py:141-142,147), built and
   //      contracted in PASSES of at most `pass_rows` rows so that the workspace stays bounded for very large n (the
   //      Gram accumulators are updated with beta = 1 from the second pass on); C4 (3.2 GB) is a single pass.
-  const int64_t off_out = (mp + 1) & ~1;
-  const int64_t ldf = (off_out + m + 1) & ~(int64_t)1;
+  // fp32 engine (nk_set_compute_dtype): the feature matrix, the prepared rows and Y as the operand of G4 are fp32; the
+  // Gram accumulators come back fp64 (nk_gemm_tn_f32.hip)
+  const bool f32 = ctx->compute_f32 != 0 && ctx->kmat_mode == 0 && d >= 32 && !ctx_recording(ctx) && m >= 4 && d >= 4;
+  const int64_t off_out = f32 ? ((mp + 3) & ~3) : ((mp + 1) & ~1);
+  const int64_t ldf = f32 ? ((off_out + m + 3) & ~(int64_t)3) : ((off_out + m + 1) & ~(int64_t)1);
+  const double felem = f32 ? 4.0 : 8.0;
   int64_t pass_rows;
   {
     const char* b = getenv("NYSKOOP_F_BUDGET_GB");
     const double budget = (b ? atof(b) : 48.0) * 1073741824.0;
-    pass_rows = (int64_t)(budget / ((double)ldf * 8.0));
+    pass_rows = (int64_t)(budget / ((double)ldf * felem));
     if (pass_rows < 1024) pass_rows = 1024;
     if (host_passes > 1) {  // pipelined upload: at least `host_passes` passes (more if the workspace budget says so)
       const int64_t per = ((n_eff + host_passes - 1) / host_passes + 1023) & ~(int64_t)1023;
@@ -952,7 +972,7 @@ static int fit_impl(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int6
   }
   const int64_t f_rows = passes.size() > 1 ? pass_rows : n_eff;
   double* F = nullptr;
-  NK_TRY(arena_alloc_t(ctx, (size_t)f_rows * ldf + 64, &F));
+  NK_TRY(arena_alloc_t(ctx, f32 ? ((size_t)f_rows * ldf + 1) / 2 + 64 : (size_t)f_rows * ldf + 64, &F));
   const bool gram_form = ctx->kmat_mode == 0 && d >= 32;
   // Gram-form kernel blocks (MFMA engine): rows centred on the landmark mean, scaled by 1/l, transposed
   int64_t maxlen = 0;
@@ -963,9 +983,11 @@ static int fit_impl(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int6
   const bool overlap_prep = gram_form && passes.size() == 1 && passes[0].size() == 1;
   if (gram_form) {
     NK_TRY(arena_alloc_t(ctx, (size_t)d, &center));
-    NK_TRY(arena_alloc_t(ctx, (size_t)d * ldt, &Rt));
-    NK_TRY(arena_alloc_t(ctx, (size_t)maxlen, &sqr));
-    if (overlap_prep) {
+    if (!f32) {
+      NK_TRY(arena_alloc_t(ctx, (size_t)d * ldt, &Rt));
+      NK_TRY(arena_alloc_t(ctx, (size_t)maxlen, &sqr));
+    }
+    if (overlap_prep && !f32) {
       NK_TRY(arena_alloc_t(ctx, (size_t)d * ldt, &Rt2));
       NK_TRY(arena_alloc_t(ctx, (size_t)maxlen, &sqr2));
     }
@@ -981,6 +1003,18 @@ static int fit_impl(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int6
       NK_TRY(arena_alloc_t(ctx, (size_t)m, &sqzi));
       NK_TRY(prep_rows(ctx, zi.ptr, zi.ld, m, d, mdl->winv, center, Zti, ldzt, sqzi));
     }
+  }
+  float *F32 = reinterpret_cast<float*>(F), *Rt32 = nullptr, *sq32 = nullptr, *Zt32 = nullptr, *sqz32 = nullptr, *Y32 = nullptr;
+  const int64_t ldt32 = (maxlen + 3) & ~(int64_t)3, ldzt32 = (m + 3) & ~3, ldy32 = (d + 3) & ~3;
+  if (f32) {
+    NK_REQUIRE(same_centers, "fp32 engine: separate input landmarks are not supported");
+    double* tmp = nullptr;
+    NK_TRY(arena_alloc_t(ctx, ((size_t)d * ldt32 + 1) / 2 + 2, &tmp)); Rt32 = reinterpret_cast<float*>(tmp);
+    NK_TRY(arena_alloc_t(ctx, ((size_t)maxlen + 1) / 2 + 2, &tmp)); sq32 = reinterpret_cast<float*>(tmp);
+    NK_TRY(arena_alloc_t(ctx, ((size_t)d * ldzt32 + 1) / 2 + 2, &tmp)); Zt32 = reinterpret_cast<float*>(tmp);
+    NK_TRY(arena_alloc_t(ctx, ((size_t)m + 1) / 2 + 2, &tmp)); sqz32 = reinterpret_cast<float*>(tmp);
+    NK_TRY(arena_alloc_t(ctx, ((size_t)f_rows * ldy32 + 1) / 2 + 2, &tmp)); Y32 = reinterpret_cast<float*>(tmp);
+    NK_TRY(prep_rows_f32(ctx, zo.ptr, zo.ld, m, d, mdl->winv, center, Zt32, ldzt32, sqz32));
   }
   const bool multi_pass = passes.size() > 1;
   const bool pipelined = host_passes > 1;
@@ -1005,6 +1039,41 @@ static int fit_impl(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int6
     const std::vector<Piece>& ps = passes[ip];
     const double beta = ip == 0 ? 0.0 : 1.0;
     if (pipelined) NK_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_up[ip & 7], 0));
+    if (f32) {
+      // -- fp32 engine: kernel blocks, then ONE fused Gram launch with fp64 results
+      int64_t o32 = 0;
+      for (const Piece& pc : ps) {
+        const double* xs = x.ptr + pc.b * x.ld;
+        const double* ys = y.ptr + pc.b * y.ld;
+        NK_TRY(prep_rows_f32(ctx, xs, x.ld, pc.len, d, mdl->winv, center, Rt32, ldt32, sq32));
+        NK_TRY(launch_kmat_gram_f32(ctx, kd->type, Rt32, ldt32, sq32, pc.len, Zt32, ldzt32, sqz32, m, d, kd->sigma0,
+                                    F32 + o32 * ldf, ldf));
+        NK_TRY(prep_rows_f32(ctx, ys, y.ld, pc.len, d, mdl->winv, center, Rt32, ldt32, sq32));
+        NK_TRY(launch_kmat_gram_f32(ctx, kd->type, Rt32, ldt32, sq32, pc.len, Zt32, ldzt32, sqz32, m, d, kd->sigma0,
+                                    F32 + o32 * ldf + off_out, ldf));
+        if (p > 0) NK_TRY(launch_cvt_f64_f32(ctx, xs + d, x.ld, F32 + o32 * ldf + m, ldf, pc.len, p));
+        NK_TRY(launch_cvt_f64_f32(ctx, ys, y.ld, Y32 + o32 * ldy32, ldy32, pc.len, d));
+        o32 += pc.len;
+      }
+      if (ip == 0) {
+        NK_HIP(hipEventRecord(ev[2], ctx->stream));
+        tr.mark("kmat issued");
+      }
+      TnProblemF pf[4];
+      pf[0].A = F32; pf[0].B = F32; pf[0].lda = pf[0].ldb = ldf; pf[0].M = pf[0].N = mp; pf[0].C = G1; pf[0].ldc = mp;
+      pf[0].tri = TRI_UPPER_MIRROR;
+      pf[1].A = F32 + off_out; pf[1].B = F32; pf[1].lda = pf[1].ldb = ldf; pf[1].M = m; pf[1].N = mp; pf[1].C = G2; pf[1].ldc = mp;
+      pf[2].A = F32 + off_out; pf[2].B = F32 + off_out; pf[2].lda = pf[2].ldb = ldf; pf[2].M = pf[2].N = m; pf[2].C = G3;
+      pf[2].ldc = m; pf[2].tri = TRI_UPPER_MIRROR;
+      pf[3].A = Y32; pf[3].lda = ldy32; pf[3].M = d; pf[3].N = m; pf[3].C = G4; pf[3].ldc = m; pf[3].B = F32 + off_out;
+      pf[3].ldb = ldf;
+      for (int q = 0; q < 4; ++q) pf[q].beta = beta;
+      float ms1 = 0.f;
+      NK_TRY(launch_gemm_tn_f32_multi(ctx, pf, 4, o32, 0, timed ? &ms1 : nullptr, multi_pass));
+      if (multi_pass) ms_gram_kernel += ms1; else gram_deferred = timed;
+      gram_launches += 1;
+      continue;
+    }
     // -- kernel blocks of this pass
     int64_t o = 0;
     for (const Piece& pc : ps) {
@@ -1124,6 +1193,21 @@ static int fit_impl(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int6
     // kernel matrices are positive semi-definite: the jitter bounds the smallest eigenvalue of K_mm + jitter I from
     // below, which lets the iteration be queued before this factorisation has run (SqrtPlan::lambda_min_hint)
     splan.lambda_min_hint = jitter > 0.0 ? jitter : 0.0;
+    // This chain of ~100 small high-priority kernels must not run beside the fused Gram launch: that launch fills the
+    // chip in exact rounds of 3-ms workgroups, and a Gram workgroup whose slot a chain kernel holds at a round boundary
+    // finds the next free slot a whole round later -- measured: the launch takes 26.5-27.0 ms inside the fit against 25.0
+    // alone.  So the chain runs its first steps beside the kernel blocks (short workgroups: a displaced one waits
+    // microseconds), pauses, and finishes after the Gram launch -- ahead of the square-root iteration, which has that
+    // much slack against the factorisation chain of the regularised systems.  NYSKOOP_PREP_PAUSE = fraction of the
+    // block steps to run before the pause (default 0.5; 1 = never pause).
+    if (mode == FIT_FULL && n_eff >= 20000 && m >= 1024) {
+      static const double frac = getenv("NYSKOOP_PREP_PAUSE") ? atof(getenv("NYSKOOP_PREP_PAUSE")) : 0.5;
+      const int nb = (m + CHOL_NB - 1) / CHOL_NB;
+      if (frac < 1.0) {
+        splan.pause_event = ctx->ev_fork;  // recorded above, behind the last Gram launch
+        splan.pause_step = std::max(0, std::min(nb - 1, (int)(frac * nb)));
+      }
+    }
     NK_TRY(sqrtm_prepare(ctx, Kj, m, m, &splan));
     NK_HIP(hipEventRecord(ev[9], ctx->stream));
   }
@@ -1944,6 +2028,37 @@ int nk_gemm(nk_ctx* ctx, int transA, int transB, int64_t M, int64_t N, int64_t K
   NK_TRY(launch_gemm(ctx, transA != 0, transB != 0, M, N, K, alpha, a.ptr, a.ld, b.ptr, b.ld, beta, c.dev, c.ld));
   NK_TRY(finish_out(ctx, c));
   NK_HIP(hipStreamSynchronize(ctx->stream));
+  return NK_OK;
+}
+
+int nk_gemm_f32(nk_ctx* ctx, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,
+                double* Cm, int64_t ldc) {
+  NK_TRY(check_ctx(ctx));
+  NK_REQUIRE(A && B && Cm && M > 0 && N > 0 && K > 0 && M < (1 << 30) && N < (1 << 30) && lda >= M && ldb >= N && ldc >= N,
+             "nk_gemm_f32: bad argument");
+  const ArenaMark mk = arena_mark(ctx);
+  const float *Ad = A, *Bd = B;
+  double* Cd = Cm;
+  double* tmp = nullptr;
+  if (!is_device_ptr(A)) {
+    NK_TRY(arena_alloc_t(ctx, ((size_t)K * lda + 1) / 2 + 2, &tmp));
+    NK_HIP(hipMemcpyAsync(tmp, A, (size_t)K * lda * 4, hipMemcpyHostToDevice, ctx->stream));
+    Ad = reinterpret_cast<const float*>(tmp);
+  }
+  if (!is_device_ptr(B)) {
+    NK_TRY(arena_alloc_t(ctx, ((size_t)K * ldb + 1) / 2 + 2, &tmp));
+    NK_HIP(hipMemcpyAsync(tmp, B, (size_t)K * ldb * 4, hipMemcpyHostToDevice, ctx->stream));
+    Bd = reinterpret_cast<const float*>(tmp);
+  }
+  const bool c_host = !is_device_ptr(Cm);
+  if (c_host) NK_TRY(arena_alloc_t(ctx, (size_t)M * ldc, &Cd));
+  TnProblemF pf;
+  pf.A = Ad; pf.B = Bd; pf.lda = lda; pf.ldb = ldb; pf.M = (int)M; pf.N = (int)N; pf.C = Cd; pf.ldc = ldc;
+  NK_REQUIRE(tnf_fast_ok(pf), "nk_gemm_f32: operands must be 16-byte aligned with leading dimensions that are multiples of 4 and >= 4 columns");
+  NK_TRY(launch_gemm_tn_f32_multi(ctx, &pf, 1, K, 0, nullptr, true));
+  if (c_host) NK_HIP(hipMemcpyAsync(Cm, Cd, (size_t)M * ldc * 8, hipMemcpyDeviceToHost, ctx->stream));
+  NK_HIP(hipStreamSynchronize(ctx->stream));
+  arena_release(ctx, mk);
   return NK_OK;
 }
 

@@ -68,6 +68,10 @@ struct nk_ctx {
   nk::Arena arena;                    // workspace of the main stream
   nk::Arena arena_side;               // workspace of the side stream (slabs must not be shared across streams)
   nk::Arena* cur_arena = nullptr;
+  hipStream_t stream_la[2] = {nullptr, nullptr};  // look-ahead streams of the blocked Cholesky: [0] beside the prep stream
+                                                  // (highest priority), [1] beside the main stream (middle)
+  hipEvent_t ev_la[2][4] = {};                    // per look-ahead stream: panel-done / rest-done events, two of each (ring)
+  int compute_f32 = 0;                            // 1: kernel blocks and Gram contractions of a fit on the fp32 engine
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int* d_info = nullptr;       // device flags for factorisation failures (one int per paired system)
   unsigned long long* d_piv = nullptr;  // [min, max] Cholesky pivot per system slot (bit patterns), behind d_info's 4 slots
@@ -219,6 +223,11 @@ struct SqrtPlan {
   // sqrtm_verdict as NK_SQRT_RETRY and the caller falls back to sqrtm_spd_coupled.
   double lambda_min_hint = 0.0;
   bool early = false;
+  // The factorisation chain of sqrtm_prepare is paused before block step `pause_step` until `pause_event` (recorded by
+  // the caller BEFORE sqrtm_prepare is called) has completed -- see nk_nystrom_fit: the chain must not run beside the
+  // fused Gram launch.
+  hipEvent_t pause_event = nullptr;
+  int pause_step = -1;
 };
 constexpr int NK_SQRT_RETRY = 1;  // internal (positive) verdict: redo the square root with the coupled iteration
 int sqrtm_spd_coupled(nk_ctx* ctx, const double* P, int64_t ldp, int m, double* S, double* Sinv, int* iters, double* resid);
@@ -252,7 +261,8 @@ int cholesky_lower_pair_async(nk_ctx* ctx, const CholSys* sys, int nsys);  // no
 int cholesky_check_pair(nk_ctx* ctx, const CholSys* sys, int nsys);       // verdict of the async factorisation
 int cholesky_solve_pair(nk_ctx* ctx, const CholSys* sys, int nsys);
 // factor + both substitutions, no host sync; mark / mark_step: optional event recorded after block step `mark_step`
-int cholesky_aug_pair_async(nk_ctx* ctx, const CholSys* sys, int nsys, hipEvent_t mark = nullptr, int mark_step = -1);
+// pause / pause_step: before block step pause_step the chain's stream waits for the (already recorded) event `pause`
+int cholesky_aug_pair_async(nk_ctx* ctx, const CholSys* sys, int nsys, hipEvent_t pause = nullptr, int pause_step = -1);
 constexpr int CHOL_NB = 64;
 // trailing update C -= P P^T (K = 64) of up to two systems (nk_trail.hip); false: not that shape, use launch_gemm_pair
 bool launch_chol_trail_pair(nk_ctx* ctx, const GemmCall* calls, int ncalls, int* rc);
@@ -341,6 +351,24 @@ struct TnSkip {
   int* resid_count = nullptr;
 };
 bool tn_fast_ok(const TnProblem& p);  // alignment / leading-dimension requirements of the LDS-DMA path
+// fp32 engine (nk_gemm_tn_f32.hip): operands fp32 contraction-major, results fp64
+struct TnProblemF {
+  const float* A = nullptr;
+  const float* B = nullptr;
+  double* C = nullptr;
+  int64_t lda = 0, ldb = 0, ldc = 0;
+  int M = 0, N = 0;
+  int tri = TRI_FULL;
+  double beta = 0.0;
+};
+bool tnf_fast_ok(const TnProblemF& p);
+int launch_gemm_tn_f32_multi(nk_ctx* ctx, const TnProblemF* probs, int nprob, int64_t K, int splitk /*0=auto*/,
+                             float* ms_kernel = nullptr, bool sync_timing = true);
+int prep_rows_f32(nk_ctx* ctx, const double* X, int64_t ldx, int64_t rows, int d, const double* winv, const double* center,
+                  float* Xt, int64_t ldt, float* sq);
+int launch_cvt_f64_f32(nk_ctx* ctx, const double* src, int64_t lds_, float* dst, int64_t ldd, int64_t rows, int cols);
+int launch_kmat_gram_f32(nk_ctx* ctx, int ktype, const float* At, int64_t ldat, const float* sqa, int64_t nA, const float* Bt,
+                         int64_t ldbt, const float* sqb, int64_t nB, int d, double sigma0, float* out, int64_t ldo);
 int launch_gemm_tn_multi(nk_ctx* ctx, const TnProblem* probs, int nprob, int64_t K, int splitk /*0=auto*/,
                          float* ms_kernel = nullptr, bool sync_timing = true, const TnSkip* skip = nullptr);
 int launch_transpose(nk_ctx* ctx, const double* src, int64_t lds, double* dst, int64_t ldd, int rows, int cols);

@@ -16,6 +16,7 @@
 //     applies alpha/beta, bounds and the symmetric mirror (deterministic; no float atomics).
 #include "nk_common.h"
 #include "nk_tn_kstep.inc"
+#include "nk_tn_shared.h"
 
 #include <cstdlib>
 #include <cstring>
@@ -24,11 +25,10 @@ namespace nk {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
-constexpr int TBM = 128, TBK = 16;
+constexpr int TBK = 16;
 constexpr int TSTRIDE = 144;                               // doubles per LDS row: conflict-free ds_read_b64 operand fetch
 constexpr int TSTAGE = 2 * TBK * TSTRIDE;                  // doubles per pipeline stage (A rows then B rows)
 constexpr int TN_LDS_BYTES = 2 * TSTAGE * 8;               // two stages
-constexpr int TN_MAXP = 4;
 
 struct TnDev {
   const double* A;
@@ -55,6 +55,7 @@ struct TnParams {
   int ntiles;
   int K, splitk, klen;
   int kmask;            // experiments only (NYSKOOP_TN_KMASK): operand rows are fetched from k & kmask; -1 = off
+  int use_asm;          // 1: the hand-scheduled k steps (default); 0: the compiler-scheduled form of the same steps (NYSKOOP_TN_ASM=0, A/B runs)
   const double* zeros;  // >= 1 KiB of zeros
   double* slab;
   // conditional launch (device-side early exit of an iteration that has already converged, no host round trip): the
@@ -95,58 +96,6 @@ __device__ __forceinline__ void dma_row(const double* row_base, uint32_t lane_of
                : "m0");
 }
 __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-
-// tile (tm, tn) of index t within a problem.  Full problems whose tile grid is a multiple of 8 x 8 are walked in 8 x 8
-// super-blocks: workgroups are dispatched in index order, so the ~64 tiles an XCD holds at a time then stream 8 + 8
-// operand panels instead of 4 + 16, and more of the panel traffic is shared through that XCD's L2.
-__device__ __forceinline__ void tn_tile_coords(int t, int tri, int tiles_n, int M, int& tm, int& tn) {
-  if (tri == TRI_FULL) {
-    const int tiles_m = (M + TBM - 1) / TBM;
-    if ((tiles_m & 7) == 0 && (tiles_n & 7) == 0) {
-      const int sb = t >> 6, w = t & 63;
-      const int sbn = tiles_n >> 3;
-      const int sbr = sb / sbn, sbc = sb - sbr * sbn;
-      tm = sbr * 8 + (w >> 3);
-      tn = sbc * 8 + (w & 7);
-    } else {
-      tm = t / tiles_n;
-      tn = t - tm * tiles_n;
-    }
-  } else if ((tiles_n & 7) == 0) {
-    // upper triangle in 8 x 8 super-blocks (I <= J, row-major over the super-blocks): 36 tiles in a diagonal super-block
-    // (its own upper triangle, row-major), 64 in the others
-    const int S = tiles_n >> 3;
-    int I = 0, J = 0, rem = t;
-    for (;;) {
-      const int cnt = (I == J) ? 36 : 64;
-      if (rem < cnt) break;
-      rem -= cnt;
-      if (++J == S) { ++I; J = I; }
-    }
-    int r, c;
-    if (I == J) {
-      r = 0;
-      while (rem >= 8 - r) {
-        rem -= 8 - r;
-        ++r;
-      }
-      c = r + rem;
-    } else {
-      r = rem >> 3;
-      c = rem & 7;
-    }
-    tm = I * 8 + r;
-    tn = J * 8 + c;
-  } else {  // upper triangle, row-major enumeration
-    int row = 0, rem = t;
-    while (rem >= tiles_n - row) {
-      rem -= tiles_n - row;
-      ++row;
-    }
-    tm = row;
-    tn = row + rem;
-  }
-}
 
 template <int EPI>
 __device__ __forceinline__ void tn_body(const TnParams& P) {
@@ -271,30 +220,41 @@ __device__ __forceinline__ void tn_body(const TnParams& P) {
   constexpr uint32_t STAGE_B = (uint32_t)TSTAGE * 8u;
   const uint32_t stra = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(pr.lda * 32));  // 4 rows, in bytes
   const uint32_t strb = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(pr.ldb * 32));
-  // steady steps: kt = 0 .. nfull - 2 (step kt issues the DMA of step kt + 1, which must be a full step); the assembly
-  // loop takes them two at a time (LDS stage 0, then 1)
+  // Steady steps: kt = 0 .. nfull - 2 (step kt issues the DMA of step kt + 1, which must be a full step).  ONE assembly
+  // block runs them two at a time (LDS stage 0, then 1), then an odd one left over (on stage 0: the pairs start at
+  // kt = 0), then -- when the K range has no partial last step -- its final full step (no DMA, no barrier).  The C++
+  // steps below only run the end of a K range that is not a multiple of 16 rows.  (One block, not one per case: with
+  // several blocks of 40 register operands each the compiler's allocation across their joins spills.)
+#define NK_TN_ACC_OPERANDS                                                                                             \
+  [c00] "+v"(acc[0][0]), [c01] "+v"(acc[0][1]), [c02] "+v"(acc[0][2]), [c03] "+v"(acc[0][3]), [c10] "+v"(acc[1][0]),   \
+      [c11] "+v"(acc[1][1]), [c12] "+v"(acc[1][2]), [c13] "+v"(acc[1][3]), [c20] "+v"(acc[2][0]),                      \
+      [c21] "+v"(acc[2][1]), [c22] "+v"(acc[2][2]), [c23] "+v"(acc[2][3]), [c30] "+v"(acc[3][0]),                      \
+      [c31] "+v"(acc[3][1]), [c32] "+v"(acc[3][2]), [c33] "+v"(acc[3][3]), [a00] "+v"(a0[0]), [a01] "+v"(a0[1]),       \
+      [a02] "+v"(a0[2]), [a03] "+v"(a0[3]), [b00] "+v"(b0[0]), [b01] "+v"(b0[1]), [b02] "+v"(b0[2]), [b03] "+v"(b0[3]), \
+      [a10] "=&v"(a1[0]), [a11] "=&v"(a1[1]), [a12] "=&v"(a1[2]), [a13] "=&v"(a1[3]), [b10] "=&v"(b1[0]),              \
+      [b11] "=&v"(b1[1]), [b12] "=&v"(b1[2]), [b13] "=&v"(b1[3])
+#define NK_TN_IN_OPERANDS                                                                                             \
+  [ard0] "v"(ard0), [brd0] "v"(brd0), [ard1] "v"(ard1), [brd1] "v"(brd1), [voa] "v"(offa), [vob] "v"(offb),           \
+      [rowa] "s"(rowa), [rowb] "s"(rowb), [stra] "s"(stra), [strb] "s"(strb), [dst0] "s"(dst0), [dst1] "s"(dst1)
+#define NK_TN_CLOBBERS "memory", "m0", "scc", "s92", "s93", "s94", "s95"
   const int nfull = (kend - kbeg) / TBK;
   int kt_start = 0;
-  if (P.kmask == -1 && nfull >= 3) {
-    uint32_t cnt = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)((nfull - 1) / 2));
-    kt_start = 2 * (int)cnt;
-    const uint64_t rowa = uniform_u64((uint64_t)(uintptr_t)(opA + (int64_t)(kbeg + TBK + wave) * pr.lda));
-    const uint64_t rowb = uniform_u64((uint64_t)(uintptr_t)(opB + (int64_t)(kbeg + TBK + wave) * pr.ldb));
+  if (P.kmask == -1 && P.use_asm && nfull >= 1) {
     const uint32_t dst0 = (uint32_t)__builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(wave * TSTRIDE) * 8u);
     const uint32_t dst1 = dst0 + STAGE_B;
     const uint32_t ard1 = ard0 + STAGE_B, brd1 = brd0 + STAGE_B;
-    asm volatile(NK_TN_KLOOP_ASM
-                 : [c00] "+v"(acc[0][0]), [c01] "+v"(acc[0][1]), [c02] "+v"(acc[0][2]), [c03] "+v"(acc[0][3]),
-                   [c10] "+v"(acc[1][0]), [c11] "+v"(acc[1][1]), [c12] "+v"(acc[1][2]), [c13] "+v"(acc[1][3]),
-                   [c20] "+v"(acc[2][0]), [c21] "+v"(acc[2][1]), [c22] "+v"(acc[2][2]), [c23] "+v"(acc[2][3]),
-                   [c30] "+v"(acc[3][0]), [c31] "+v"(acc[3][1]), [c32] "+v"(acc[3][2]), [c33] "+v"(acc[3][3]),
-                   [a00] "+v"(a0[0]), [a01] "+v"(a0[1]), [a02] "+v"(a0[2]), [a03] "+v"(a0[3]),
-                   [b00] "+v"(b0[0]), [b01] "+v"(b0[1]), [b02] "+v"(b0[2]), [b03] "+v"(b0[3]),
-                   [a10] "=&v"(a1[0]), [a11] "=&v"(a1[1]), [a12] "=&v"(a1[2]), [a13] "=&v"(a1[3]),
-                   [b10] "=&v"(b1[0]), [b11] "=&v"(b1[1]), [b12] "=&v"(b1[2]), [b13] "=&v"(b1[3]), [cnt] "+s"(cnt)
-                 : [ard0] "v"(ard0), [brd0] "v"(brd0), [ard1] "v"(ard1), [brd1] "v"(brd1), [voa] "v"(offa), [vob] "v"(offb),
-                   [rowa] "s"(rowa), [rowb] "s"(rowb), [stra] "s"(stra), [strb] "s"(strb), [dst0] "s"(dst0), [dst1] "s"(dst1)
-                 : "memory", "m0", "scc", "s92", "s93", "s94", "s95");
+    const int steady = nfull - 1;
+    uint32_t cnt = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(steady / 2));
+    const uint32_t flags =
+        (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)((steady & 1) | (nfull == ktiles ? 2 : 0)));
+    kt_start = 2 * (int)cnt + (int)(flags & 1) + (int)(flags >> 1);
+    const uint64_t rowa = uniform_u64((uint64_t)(uintptr_t)(opA + (int64_t)(kbeg + TBK + wave) * pr.lda));
+    const uint64_t rowb = uniform_u64((uint64_t)(uintptr_t)(opB + (int64_t)(kbeg + TBK + wave) * pr.ldb));
+    if (kt_start > 0)
+      asm volatile(NK_TN_KSTEPS_ASM
+                   : NK_TN_ACC_OPERANDS, [cnt] "+s"(cnt)
+                   : NK_TN_IN_OPERANDS, [flags] "s"(flags)
+                   : NK_TN_CLOBBERS);
   }
   for (int kt = kt_start; kt < ktiles; ++kt) {
     const int st = kt & 1;
@@ -420,30 +380,9 @@ static nk::TwinReg gram_fused_twin_reg(reinterpret_cast<const void*>(static_cast
                                        reinterpret_cast<const void*>(gram_fused_f64_kernel_batched),
                                        sizeof(nk::ArgPack<TnParams>), "gram_fused_f64_kernel");
 
-struct TnRed {
-  double* C;
-  double* Ct;
-  double* Caff;  // see TnDev
-  double aff_a, aff_c;
-  int64_t ldc, ldct;
-  int M, N, tiles_n, tri, tile_begin;
-  double alpha, beta;
-};
-struct TnRedParams {
-  TnRed p[TN_MAXP];
-  int nprob, splitk;
-  const double* slab;
-  const double* skip_state;  // see TnParams
-  int skip_step;
-  // optional (single symmetric problem): every workgroup leaves sum (C - I)^2 over its band in resid_partials[block]
-  // (mirrored tiles counted twice), for a convergence check of ||C - I||_F without a separate pass over C
-  double* resid_partials;
-};
-
 // C = alpha * sum_s slab[tile][s] + beta * C (bounds, mirror, transposed copy).  RPARTS workgroups per tile, each summing
 // a 16-row band of the slices in slice order (deterministic) with 16-byte loads; the mirrored / transposed copies go
 // through LDS so that their stores are 64-byte runs instead of single strided doubles.
-constexpr int RPARTS = 8;
 __device__ __forceinline__ void gemm_tn_reduce_kernel_body(const TnRedParams& P) {
   __shared__ double sh[16][130];
   if (P.skip_state != nullptr) {
@@ -527,6 +466,12 @@ static nk::TwinReg gemm_tn_reduce_twin_reg(reinterpret_cast<const void*>(static_
                                            reinterpret_cast<const void*>(gemm_tn_reduce_kernel_batched),
                                            sizeof(nk::ArgPack<TnRedParams>), "gemm_tn_reduce_kernel");
 
+int launch_tn_reduce(nk_ctx* ctx, const TnRedParams& R, int ntiles) {
+  hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((unsigned)ntiles * RPARTS), dim3(256), 0, ctx->stream, R);
+  NK_HIP(hipGetLastError());
+  return NK_OK;
+}
+
 // 32x32 tiled transpose through LDS
 __device__ __forceinline__ void transpose_kernel_body(const double* __restrict__ src, int64_t lds_, double* __restrict__ dst, int64_t ldd, int rows, int cols) {
   __shared__ double tile[32][33];
@@ -561,8 +506,12 @@ bool tn_fast_ok(const TnProblem& p) {
 }
 
 static bool g_tn_attr_set = false;
+static int tn_use_asm() {
+  const char* e = getenv("NYSKOOP_TN_ASM");  // read per launch: A/B runs flip it inside one process
+  return (e && e[0] == '0') ? 0 : 1;
+}
 
-static int ensure_zero_page(nk_ctx* ctx) {
+int tn_ensure_zero_page(nk_ctx* ctx) {
   if (ctx->d_zeros) return NK_OK;
   NK_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->d_zeros), 4096));
   NK_HIP(hipMemset(ctx->d_zeros, 0, 4096));  // blocking: both streams of the context read this page
@@ -573,7 +522,7 @@ int launch_gemm_tn_multi(nk_ctx* ctx, const TnProblem* probs, int nprob, int64_t
                          bool sync_timing, const TnSkip* skip) {
   NK_REQUIRE(nprob >= 1 && nprob <= TN_MAXP, "gemm_tn_multi: 1..4 problems");
   NK_REQUIRE(K >= 0 && K < (1LL << 31), "gemm_tn_multi: K out of range");
-  NK_TRY(ensure_zero_page(ctx));
+  NK_TRY(tn_ensure_zero_page(ctx));
   TnParams P;
   TnRedParams R;
   int ntiles = 0;
@@ -629,6 +578,7 @@ int launch_gemm_tn_multi(nk_ctx* ctx, const TnProblem* probs, int nprob, int64_t
   if (want_resid && splitk < 2) splitk = 2;  // the residual partials come out of the reduce kernel
   if (nprob >= 3 && getenv("NYSKOOP_TN_SPLITK")) splitk = atoi(getenv("NYSKOOP_TN_SPLITK"));  // experiments
   P.kmask = getenv("NYSKOOP_TN_KMASK") ? (int)strtol(getenv("NYSKOOP_TN_KMASK"), nullptr, 0) : -1;
+  P.use_asm = tn_use_asm();
   P.nprob = nprob; P.ntiles = ntiles; P.K = (int)K; P.splitk = splitk;
   P.klen = ((ktiles_total + splitk - 1) / splitk) * TBK;
   if (P.klen == 0) P.klen = TBK;
@@ -783,7 +733,7 @@ int prep_rows(nk_ctx* ctx, const double* X, int64_t ldx, int64_t rows, int d, co
 int launch_kmat_gram(nk_ctx* ctx, int ktype, const double* At, int64_t ldat, const double* sqa, int64_t nA,
                      const double* Bt, int64_t ldbt, const double* sqb, int64_t nB, int d, double sigma0, double* out,
                      int64_t ldo) {
-  NK_TRY(ensure_zero_page(ctx));
+  NK_TRY(tn_ensure_zero_page(ctx));
   TnProblem tp;
   tp.A = At; tp.B = Bt; tp.lda = ldat; tp.ldb = ldbt; tp.M = (int)nA; tp.N = (int)nB;
   NK_REQUIRE(tn_fast_ok(tp), "kmat_gram: operands violate the alignment contract");
@@ -795,7 +745,7 @@ int launch_kmat_gram(nk_ctx* ctx, int ktype, const double* At, int64_t ldat, con
   dv.tile_begin = 0; dv.ktrim = KTRIM_NONE; dv.A_even = dv.B_even = nullptr; dv.Caff = nullptr; dv.aff_a = dv.aff_c = 0.0;
   dv.C = nullptr; dv.ldc = 0; dv.alpha = 1.0; dv.beta = 0.0; dv.Ct = nullptr; dv.ldct = 0;
   for (int q = 1; q < TN_MAXP; ++q) { P.p[q] = P.p[0]; P.p[q].tile_begin = 1 << 30; }
-  P.nprob = 1; P.ntiles = tmn * tnn; P.K = d; P.splitk = 1; P.kmask = -1;
+  P.nprob = 1; P.ntiles = tmn * tnn; P.K = d; P.splitk = 1; P.kmask = -1; P.use_asm = tn_use_asm();
   P.klen = ((d + TBK - 1) / TBK) * TBK;
   P.zeros = ctx->d_zeros; P.slab = nullptr;
   P.sqa = sqa; P.sqb = sqb; P.out = out; P.ldo = ldo; P.ktype = ktype; P.sigma0sq = sigma0 * sigma0;

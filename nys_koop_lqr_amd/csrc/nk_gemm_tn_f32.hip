@@ -1,0 +1,440 @@
+// fp32 TN engine for the stress configuration (BASELINE.json configs[4]: n = 1e6, m = 8000, d = 1024, "fp32, K_nm streamed in
+// HBM-resident tiles"): the two O(n m d) kernel blocks and the O(n m^2) Gram contractions of a fit (regressors.py:141-142,
+// 151,153,162,164) on v_mfma_f32_32x32x2_f32 -- twice the rate of the fp64 matrix pipe, half the bytes of every operand.
+// Everything m x m (the regularised systems, the square root, the operators) stays fp64: the Gram accumulators leave this
+// engine as fp64 (each workgroup moves its fp32 accumulators into fp64 shadow registers every `flush_steps` k-steps, so
+// no fp32 sum runs over more than a few thousand rows; partial tiles and their reduction are fp64, shared with the fp64
+// engine).  Opt-in only (nk_set_compute_dtype): fp32 cannot reach the 1e-6 operator bar of the fp64 path.
+//
+// Same structure as nk_gemm_tn.hip: C = A^T B with both operands contraction-major (rows = k), 128 x 128 tile, 256 threads
+// (2 x 2 waves, 64 x 64 each = 2 x 2 MFMA blocks of 32 x 32), k-steps of 32 rows (the same 64 MFMAs of 64 cycles per wave
+// and step as the fp64 engine), two LDS stages filled by LDS-DMA -- one instruction moves TWO k-rows (lanes 0-31 row
+// k, lanes 32-63 row k + 1: 2 x 512 B, contiguous in the unpadded LDS image) -- operand fragments fetched one k-pair
+// ahead of the MFMAs that use them, one barrier per step.
+#include "nk_common.h"
+#include "nk_tn_shared.h"
+
+#include <cstdlib>
+
+namespace nk {
+
+typedef float f16v __attribute__((ext_vector_type(16)));
+
+constexpr int FBK = 32;                    // contraction rows per k-step
+constexpr int FROW = 128;                  // floats per LDS row (no padding: a wave reads one k-row per 32-lane pass)
+constexpr int FPANEL = FBK * FROW;         // floats per operand panel of a stage
+constexpr int FSTAGE = 2 * FPANEL;         // A panel, then B panel
+constexpr int F32_LDS_BYTES = 2 * FSTAGE * 4;  // two stages: 64 KiB
+
+struct TnDevF {
+  const float* A;
+  const float* B;
+  int64_t lda, ldb;
+  int M, N;
+  int tiles_n, tri, tile_begin;
+  double* C;  // direct epilogue (splitk == 1): C = acc + beta * C
+  int64_t ldc;
+  double beta;
+};
+struct TnParamsF {
+  TnDevF p[TN_MAXP];
+  int nprob, ntiles;
+  int K, splitk, klen;
+  int flush_steps;      // fp32 accumulators are added into the fp64 shadow every this many k-steps
+  const float* zeros;   // >= 1 KiB of zeros (rows past the K range)
+  double* slab;         // [tile][slice][128][128] fp64 partial tiles
+  // kernel-matrix epilogue (EPI >= 1): out[i][j] = k(sqa[i] + sqb[j] - 2 acc), fp32
+  const float* sqa;
+  const float* sqb;
+  float* out;
+  int64_t ldo;
+  float sigma0sq;
+};
+
+__device__ __forceinline__ void dma2_rows(const float* lane_src, uint32_t lds_addr) {
+  // 64 lanes x 16 bytes -> LDS [lds_addr, lds_addr + 1 KiB): two k-rows of 128 floats (see the file header)
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+               :
+               : "v"(lane_src), "s"((uint32_t)__builtin_amdgcn_readfirstlane(lds_addr))
+               : "m0");
+}
+__device__ __forceinline__ void dma_wait_all_f() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+template <int EPI>
+__device__ __forceinline__ void tnf_body(const TnParamsF& P) {
+  extern __shared__ __attribute__((aligned(16))) float fsmem[];
+  const int split = blockIdx.x % P.splitk;
+  const int gt = blockIdx.x / P.splitk;
+  int pi = 0;
+#pragma unroll
+  for (int q = 1; q < TN_MAXP; ++q)
+    if (q < P.nprob && gt >= P.p[q].tile_begin) pi = q;
+  const TnDevF pr = P.p[pi];
+  int tm, tn;
+  if (EPI >= 1) {  // kernel-matrix launch: every XCD group owns its landmark tile columns (see nk_gemm_tn.hip)
+    const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;
+    const int cols = (pr.tiles_n - xcd + 7) >> 3;
+    if (cols <= 0) return;
+    tm = i / cols;
+    tn = xcd + 8 * (i - tm * cols);
+    if (tm * TBM >= pr.M) return;
+  } else {
+    tn_tile_coords(gt - pr.tile_begin, pr.tri, pr.tiles_n, pr.M, tm, tn);
+  }
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int half = lane >> 5, l32 = lane & 31;
+  const int kbeg = split * P.klen;
+  const int kend = min(P.K, kbeg + P.klen);
+  const int ktiles = kend > kbeg ? (kend - kbeg + FBK - 1) / FBK : 0;
+
+  // per-lane source columns (4 floats per lane), clamped into the valid, 16-byte aligned range
+  const int ca = min(tm * TBM + l32 * 4, (pr.M - 1) & ~3);
+  const int cb = min(tn * TBM + l32 * 4, (pr.N - 1) & ~3);
+  const float* zsrc = P.zeros + l32 * 4;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)fsmem;
+
+  // wave w moves row pairs w, w + 4, w + 8, w + 12 of the A panel and of the B panel
+  auto issue = [&](int kt, int stage) {
+    const uint32_t sa = lds0 + (uint32_t)(stage * FSTAGE) * 4u;
+    const uint32_t sb = sa + (uint32_t)FPANEL * 4u;
+    const int k0 = kbeg + kt * FBK;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int rp = wave + 4 * q;          // row pair
+      const int k = k0 + 2 * rp + half;     // this lane's row
+      const bool ok = k < kend;
+      const float* ga = ok ? pr.A + (int64_t)k * pr.lda + ca : zsrc;
+      const float* gb = ok ? pr.B + (int64_t)k * pr.ldb + cb : zsrc;
+      dma2_rows(ga, sa + (uint32_t)(2 * rp * FROW) * 4u);
+      dma2_rows(gb, sb + (uint32_t)(2 * rp * FROW) * 4u);
+    }
+  };
+
+  f16v acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+  double sh[2][2][16];  // fp64 shadow of the accumulators (Gram launches only)
+  if (EPI == 0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) sh[i][j][v] = 0.0;
+  }
+
+  const int wm = wave >> 1, wn = wave & 1;
+  // fragments of k-pair kk (rows 2 kk, 2 kk + 1 of the stage): lane (half, l32) holds A[2 kk + half][.. + l32]
+  auto frag = [&](int stage, int kk, float (&a)[2], float (&b)[2]) {
+    const float* ab = fsmem + stage * FSTAGE + (2 * kk + half) * FROW + l32;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) a[i] = ab[wm * 64 + i * 32];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) b[j] = ab[FPANEL + wn * 64 + j * 32];
+  };
+  auto mma = [&](const float (&a)[2], const float (&b)[2]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+  };
+
+  float a0[2], b0[2], a1[2], b1[2];
+  if (ktiles > 0) {
+    issue(0, 0);
+    dma_wait_all_f();
+    __syncthreads();
+    frag(0, 0, a0, b0);
+  }
+  int since_flush = 0;
+  for (int kt = 0; kt < ktiles; ++kt) {
+    const int st = kt & 1;
+    const bool more = kt + 1 < ktiles;
+    if (more) issue(kt + 1, st ^ 1);  // everybody left stage st^1 at the barrier of the previous step
+#pragma unroll
+    for (int kk = 0; kk < FBK / 2; kk += 2) {
+      frag(st, kk + 1, a1, b1);
+      mma(a0, b0);
+      if (kk + 2 < FBK / 2) {
+        frag(st, kk + 2, a0, b0);
+        mma(a1, b1);
+      }
+    }
+    // all reads of stage st are in registers (a1 / b1 hold the last k-pair): the barrier, then the first fragments of the
+    // next stage in the shadow of the last four MFMAs
+    dma_wait_all_f();
+    __syncthreads();
+    if (more) frag(st ^ 1, 0, a0, b0);
+    mma(a1, b1);
+    if (EPI == 0 && ++since_flush >= P.flush_steps) {
+      since_flush = 0;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int v = 0; v < 16; ++v) {
+            sh[i][j][v] += (double)acc[i][j][v];
+            acc[i][j][v] = 0.f;
+          }
+    }
+  }
+
+  // element (block i, j; register v) of a wave's 64 x 64 sub-tile: row = i*32 + 8*(v/4) + 4*half + v%4, col = j*32 + l32
+  if (EPI == 0) {
+    const bool direct = P.splitk == 1;
+    const bool mirror = direct && pr.tri == TRI_UPPER_MIRROR && tm != tn;
+    double* out = direct ? nullptr : P.slab + ((int64_t)gt * P.splitk + split) * (TBM * TBM);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          const int r = wm * 64 + i * 32 + 8 * (v >> 2) + 4 * half + (v & 3);
+          const int c = wn * 64 + j * 32 + l32;
+          const double val = sh[i][j][v] + (double)acc[i][j][v];
+          if (!direct) {
+            out[r * TBM + c] = val;
+          } else {
+            const int row = tm * TBM + r, col = tn * TBM + c;
+            if (row < pr.M && col < pr.N) {
+              double w = val;
+              if (pr.beta != 0.0) w += pr.beta * pr.C[(int64_t)row * pr.ldc + col];
+              pr.C[(int64_t)row * pr.ldc + col] = w;
+              if (mirror) pr.C[(int64_t)col * pr.ldc + row] = w;
+            }
+          }
+        }
+  } else {
+    // kernel-matrix epilogue (EPI = 1 RBF, 2 Matern-5/2, 3 linear) in fp32
+    float sbv[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = tn * TBM + wn * 64 + j * 32 + l32;
+      sbv[j] = (EPI != 3 && col < pr.N) ? P.sqb[col] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const int row = tm * TBM + wm * 64 + i * 32 + 8 * (v >> 2) + 4 * half + (v & 3);
+        if (row >= pr.M) continue;
+        const float sav = EPI != 3 ? P.sqa[row] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int col = tn * TBM + wn * 64 + j * 32 + l32;
+          const float dot = acc[i][j][v];
+          float val;
+          if (EPI == 3) {
+            val = dot + P.sigma0sq;
+          } else {
+            const float D = fmaxf(sav + sbv[j] - 2.f * dot, 0.f);
+            if (EPI == 1) {
+              val = expf(-0.5f * D);
+            } else {
+              const float t = sqrtf(D) * 2.2360679774997896f;
+              val = (1.f + t + t * t * (1.f / 3.f)) * expf(-t);
+            }
+          }
+          if (col < pr.N) P.out[(int64_t)row * P.ldo + col] = val;
+        }
+      }
+  }
+}
+
+template <int EPI>
+__global__ void __launch_bounds__(256, 2) gemm_tn_f32_kernel(TnParamsF P) {
+  tnf_body<EPI>(P);
+}
+// the fit's fused Gram launch in fp32, under its own name for the profiler
+__global__ void __launch_bounds__(256, 2) gram_fused_f32_kernel(TnParamsF P) { tnf_body<0>(P); }
+
+bool tnf_fast_ok(const TnProblemF& p) {
+  auto al = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  return p.M >= 4 && p.N >= 4 && al(p.A) && al(p.B) && p.lda % 4 == 0 && p.ldb % 4 == 0 && p.lda >= ((p.M + 3) & ~3) &&
+         p.ldb >= ((p.N + 3) & ~3);
+}
+
+static int tnf_attrs() {
+  static bool done = false;
+  if (done) return NK_OK;
+  NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_f32_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, F32_LDS_BYTES));
+  NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_f32_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, F32_LDS_BYTES));
+  NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_f32_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, F32_LDS_BYTES));
+  NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_f32_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, F32_LDS_BYTES));
+  NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gram_fused_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, F32_LDS_BYTES));
+  done = true;
+  return NK_OK;
+}
+
+// C_q (fp64) = A_q^T B_q (+ beta C_q) for up to 4 problems that share K, operands fp32 contraction-major.
+int launch_gemm_tn_f32_multi(nk_ctx* ctx, const TnProblemF* probs, int nprob, int64_t K, int splitk, float* ms_kernel,
+                             bool sync_timing) {
+  NK_REQUIRE(nprob >= 1 && nprob <= TN_MAXP, "gemm_tn_f32_multi: 1..4 problems");
+  NK_REQUIRE(K >= 0 && K < (1LL << 31), "gemm_tn_f32_multi: K out of range");
+  NK_REQUIRE(!ctx_recording(ctx), "gemm_tn_f32_multi: the fp32 engine is not available inside a lock-step group");
+  NK_TRY(tn_ensure_zero_page(ctx));
+  NK_TRY(tnf_attrs());
+  TnParamsF P;
+  TnRedParams R;
+  int ntiles = 0;
+  for (int q = 0; q < nprob; ++q) {
+    const TnProblemF& s = probs[q];
+    NK_REQUIRE(tnf_fast_ok(s), "gemm_tn_f32_multi: problem %d violates the alignment contract", q);
+    NK_REQUIRE(s.tri == TRI_FULL || (s.tri == TRI_UPPER_MIRROR && s.M == s.N), "gemm_tn_f32_multi: bad tri mode");
+    const int tmn = (s.M + TBM - 1) / TBM, tnn = (s.N + TBM - 1) / TBM;
+    TnDevF& d = P.p[q];
+    d.A = s.A; d.B = s.B; d.lda = s.lda; d.ldb = s.ldb; d.M = s.M; d.N = s.N; d.tiles_n = tnn; d.tri = s.tri;
+    d.tile_begin = ntiles; d.C = s.C; d.ldc = s.ldc; d.beta = s.beta;
+    TnRed& r = R.p[q];
+    r.C = s.C; r.Ct = nullptr; r.Caff = nullptr; r.aff_a = r.aff_c = 0.0; r.ldc = s.ldc; r.ldct = 0; r.M = s.M; r.N = s.N;
+    r.tiles_n = tnn; r.tri = s.tri; r.tile_begin = ntiles; r.alpha = 1.0; r.beta = s.beta;
+    ntiles += s.tri == TRI_FULL ? tmn * tnn : tmn * (tmn + 1) / 2;
+  }
+  for (int q = nprob; q < TN_MAXP; ++q) {
+    P.p[q] = P.p[0]; P.p[q].tile_begin = 1 << 30;
+    R.p[q] = R.p[0]; R.p[q].tile_begin = 1 << 30;
+  }
+  const int ktiles_total = (int)((K + FBK - 1) / FBK);
+  if (splitk <= 0) {
+    // K slices: the fewest (1, 2, 4, then multiples of 8: one K range per XCD) that fill at least 95 % of the workgroup
+    // slots of the rounds they need, while a slice keeps at least 8 k-steps
+    const int64_t slots = 2 * ctx->num_cu;
+    splitk = 1;
+    double best_eff = 0.0;
+    for (int c : {1, 2, 4, 8, 16, 24, 32, 40, 48, 56, 64}) {
+      if (c > 1 && ktiles_total / c < 8) break;
+      const int64_t wgs = (int64_t)ntiles * c;
+      const int64_t rounds = (wgs + slots - 1) / slots;
+      const double eff = (double)wgs / (double)(rounds * slots);
+      if (eff > best_eff + 1e-9) { best_eff = eff; splitk = c; }
+      if (eff >= 0.95) break;
+    }
+  }
+  P.nprob = nprob; P.ntiles = ntiles; P.K = (int)K; P.splitk = splitk;
+  P.klen = ((ktiles_total + splitk - 1) / splitk) * FBK;
+  if (P.klen == 0) P.klen = FBK;
+  P.flush_steps = getenv("NYSKOOP_F32_FLUSH") ? atoi(getenv("NYSKOOP_F32_FLUSH")) : 32;  // 1024 rows per fp32 partial sum
+  if (P.flush_steps < 1) P.flush_steps = 1;
+  P.zeros = reinterpret_cast<const float*>(ctx->d_zeros);
+  const ArenaMark mark = arena_mark(ctx);
+  double* slab = nullptr;
+  if (splitk > 1) NK_TRY(arena_alloc_t(ctx, (size_t)ntiles * splitk * TBM * TBM, &slab));
+  P.slab = slab;
+  P.sqa = P.sqb = nullptr; P.out = nullptr; P.ldo = 0; P.sigma0sq = 0.f;
+  R.nprob = nprob; R.splitk = splitk; R.slab = slab; R.skip_state = nullptr; R.skip_step = 0; R.resid_partials = nullptr;
+  if (ms_kernel) NK_HIP(hipEventRecord(ctx->ev[14], ctx->stream));
+  if (nprob >= 3)
+    hipLaunchKernelGGL(gram_fused_f32_kernel, dim3((unsigned)(ntiles * splitk)), dim3(256), F32_LDS_BYTES, ctx->stream, P);
+  else
+    hipLaunchKernelGGL(gemm_tn_f32_kernel<0>, dim3((unsigned)(ntiles * splitk)), dim3(256), F32_LDS_BYTES, ctx->stream, P);
+  NK_HIP(hipGetLastError());
+  if (ms_kernel) NK_HIP(hipEventRecord(ctx->ev[15], ctx->stream));
+  if (splitk > 1) NK_TRY(launch_tn_reduce(ctx, R, ntiles));
+  if (ms_kernel && sync_timing) {
+    NK_HIP(hipEventSynchronize(ctx->ev[15]));
+    NK_HIP(hipEventElapsedTime(ms_kernel, ctx->ev[14], ctx->ev[15]));
+  }
+  arena_release(ctx, mark);
+  return NK_OK;
+}
+
+// ---- preparation of the rows for the Gram-form kernel blocks: centred, scaled by 1 / lengthscale, rounded to fp32 and
+//      transposed to contraction-major (d x rows), squared norms of the ROUNDED rows (so that |a|^2 + |b|^2 - 2 a.b is the
+//      squared distance of the points the engine actually multiplies) -------------------------------------------------
+__global__ void __launch_bounds__(256) prep_rows_f32_kernel(const double* __restrict__ X, int64_t ldx, int rows, int d,
+                                                            const double* __restrict__ winv, const double* __restrict__ center,
+                                                            float* __restrict__ Xt, int64_t ldt) {
+  __shared__ float tile[32][33];
+  const int k0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int r = ty; r < 32; r += 8) {
+    const int row = r0 + r, k = k0 + tx;
+    if (row < rows && k < d) tile[r][tx] = (float)((X[(int64_t)row * ldx + k] - center[k]) * winv[k]);
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int k = k0 + r, row = r0 + tx;
+    if (k < d && row < rows) Xt[(int64_t)k * ldt + row] = tile[tx][r];
+  }
+}
+__global__ void __launch_bounds__(256) colsq_f32_kernel(const float* __restrict__ Xt, int64_t ldt, int rows, int d,
+                                                        float* __restrict__ sq) {
+  __shared__ double part[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + lane;
+  double s = 0.0;
+  if (i < rows)
+    for (int k = w; k < d; k += 4) {
+      const double v = (double)Xt[(int64_t)k * ldt + i];
+      s = fma(v, v, s);
+    }
+  part[w][lane] = s;
+  __syncthreads();
+  if (w == 0 && i < rows) sq[i] = (float)((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]));
+}
+// dst (fp32, leading dimension ldd) = src (fp64, leading dimension lds), rows x cols
+__global__ void __launch_bounds__(256) cvt_f64_f32_kernel(const double* __restrict__ src, int64_t lds_, float* __restrict__ dst,
+                                                          int64_t ldd, int64_t rows, int cols) {
+  const int64_t total = rows * cols;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = t / cols;
+    const int c = (int)(t - r * cols);
+    dst[r * ldd + c] = (float)src[r * lds_ + c];
+  }
+}
+
+int prep_rows_f32(nk_ctx* ctx, const double* X, int64_t ldx, int64_t rows, int d, const double* winv, const double* center,
+                  float* Xt, int64_t ldt, float* sq) {
+  dim3 grid((d + 31) / 32, (unsigned)((rows + 31) / 32));
+  hipLaunchKernelGGL(prep_rows_f32_kernel, grid, dim3(256), 0, ctx->stream, X, ldx, (int)rows, d, winv, center, Xt, ldt);
+  hipLaunchKernelGGL(colsq_f32_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(256), 0, ctx->stream, Xt, ldt, (int)rows, d, sq);
+  NK_HIP(hipGetLastError());
+  return NK_OK;
+}
+int launch_cvt_f64_f32(nk_ctx* ctx, const double* src, int64_t lds_, float* dst, int64_t ldd, int64_t rows, int cols) {
+  if (rows <= 0 || cols <= 0) return NK_OK;
+  const int64_t total = rows * cols;
+  const unsigned grid = (unsigned)std::min<int64_t>((total + 255) / 256, 65536);
+  hipLaunchKernelGGL(cvt_f64_f32_kernel, dim3(grid), dim3(256), 0, ctx->stream, src, lds_, dst, ldd, rows, cols);
+  NK_HIP(hipGetLastError());
+  return NK_OK;
+}
+
+int launch_kmat_gram_f32(nk_ctx* ctx, int ktype, const float* At, int64_t ldat, const float* sqa, int64_t nA, const float* Bt,
+                         int64_t ldbt, const float* sqb, int64_t nB, int d, double sigma0, float* out, int64_t ldo) {
+  NK_REQUIRE(!ctx_recording(ctx), "kmat_gram_f32: the fp32 engine is not available inside a lock-step group");
+  NK_TRY(tn_ensure_zero_page(ctx));
+  NK_TRY(tnf_attrs());
+  TnProblemF tp;
+  tp.A = At; tp.B = Bt; tp.lda = ldat; tp.ldb = ldbt; tp.M = (int)nA; tp.N = (int)nB;
+  NK_REQUIRE(tnf_fast_ok(tp), "kmat_gram_f32: operands violate the alignment contract");
+  TnParamsF P;
+  const int tmn = (int)((nA + TBM - 1) / TBM), tnn = (int)((nB + TBM - 1) / TBM);
+  TnDevF& dv = P.p[0];
+  dv.A = At; dv.B = Bt; dv.lda = ldat; dv.ldb = ldbt; dv.M = (int)nA; dv.N = (int)nB; dv.tiles_n = tnn; dv.tri = TRI_FULL;
+  dv.tile_begin = 0; dv.C = nullptr; dv.ldc = 0; dv.beta = 0.0;
+  for (int q = 1; q < TN_MAXP; ++q) { P.p[q] = P.p[0]; P.p[q].tile_begin = 1 << 30; }
+  P.nprob = 1; P.ntiles = tmn * tnn; P.K = d; P.splitk = 1;
+  P.klen = ((d + FBK - 1) / FBK) * FBK;
+  P.flush_steps = 1 << 30;
+  P.zeros = reinterpret_cast<const float*>(ctx->d_zeros); P.slab = nullptr;
+  P.sqa = sqa; P.sqb = sqb; P.out = out; P.ldo = ldo; P.sigma0sq = (float)(sigma0 * sigma0);
+  const unsigned grid = 8u * (unsigned)tmn * (unsigned)((tnn + 7) / 8);
+  if (ktype == NK_KERNEL_RBF)
+    hipLaunchKernelGGL(gemm_tn_f32_kernel<1>, dim3(grid), dim3(256), F32_LDS_BYTES, ctx->stream, P);
+  else if (ktype == NK_KERNEL_MATERN52)
+    hipLaunchKernelGGL(gemm_tn_f32_kernel<2>, dim3(grid), dim3(256), F32_LDS_BYTES, ctx->stream, P);
+  else
+    hipLaunchKernelGGL(gemm_tn_f32_kernel<3>, dim3(grid), dim3(256), F32_LDS_BYTES, ctx->stream, P);
+  NK_HIP(hipGetLastError());
+  return NK_OK;
+}
+
+}  // namespace nk

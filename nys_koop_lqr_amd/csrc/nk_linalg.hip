@@ -556,20 +556,48 @@ int cholesky_lower_pair(nk_ctx* ctx, const CholSys* sys, int nsys) {
 // those rows.  Per block step: potrf (both systems), panel, trailing; the backward pass is a single launch in which
 // every workgroup carries a band of rows through the whole substitution.  The separate forward substitution
 // (2 launches per block) disappears.
-int cholesky_aug_pair_async(nk_ctx* ctx, const CholSys* sys, int nsys, hipEvent_t mark, int mark_step) {
+//
+// LOOK-AHEAD.  The chain is latency bound: per block step a one-wave diagonal factorisation (~42 us), the panel product
+// (~12 us) and the rank-64 trailing update (~33 us), each waiting for the one before.  Only the NEXT block column of the
+// trailing matrix is needed to go on, so the update is split: the next 64 columns are updated on the chain's own stream
+// (one tile column), the rest of the trailing matrix on a second stream of the same priority, beside the next step's
+// diagonal block and panel.  Dependencies: rest(j) needs panel(j) [event P] and rest(j-1) [stream order]; the narrow update
+// of step j needs rest(j-1) [event R] -- the column it touches received its older updates there.  Members of a lock-step
+// group record everything into one sequence (events are no-ops there), which is a valid order of the same graph.
+int cholesky_aug_pair_async(nk_ctx* ctx, const CholSys* sys, int nsys, hipEvent_t pause, int pause_step) {
   constexpr int NB = CHOL_NB;
   NK_REQUIRE(nsys >= 1 && nsys <= 2, "cholesky_aug_pair: 1..2 systems");
   NK_TRY(reset_pivots(ctx));
   int nblk = 0;
   for (int q = 0; q < nsys; ++q) nblk = std::max(nblk, (sys[q].m + NB - 1) / NB);
+  // Measured inside the headline fit (bench.py, same box): with the look-ahead the fit is 1.4 ms SLOWER -- the chain shares
+  // the chip with the square-root iteration's GEMMs, its kernels crawl for lack of issue slots rather than for lack of
+  // parallelism, and a second stream of them takes more from the GEMMs than the shorter dependency chain gives back.
+  // Off by default; NYSKOOP_CHOL_LOOKAHEAD=1 turns it on for chains on the main stream (a stand-alone nk_solve_spd on an
+  // idle chip gains from it).
+  static const bool la_env = getenv("NYSKOOP_CHOL_LOOKAHEAD") && getenv("NYSKOOP_CHOL_LOOKAHEAD")[0] == '1';
+  // which look-ahead stream pairs with the current one (none for callers on other streams)
+  const int la = ctx->stream == ctx->stream_main ? 1 : -1;
+  const bool lookahead = la_env && la >= 0 && nblk >= 4 && !ctx_recording(ctx);
+  hipStream_t s_chain = ctx->stream;
+  hipStream_t s_rest = lookahead ? ctx->stream_la[la] : ctx->stream;
+  hipEvent_t* ev = lookahead ? ctx->ev_la[la] : nullptr;  // [0..1] panel done (parity of the step), [2..3] rest done
+  bool rest_pending = false;
+  hipEvent_t last_rest = nullptr;
+  if (lookahead) {  // the look-ahead stream starts behind whatever the chain's stream has queued so far
+    NK_HIP(hipEventRecord(ev[1], s_chain));
+    NK_HIP(hipStreamWaitEvent(s_rest, ev[1], 0));
+  }
   for (int jb = 0; jb < nblk; ++jb) {
+    if (pause != nullptr && jb == pause_step) NK_HIP(hipStreamWaitEvent(ctx->stream, pause, 0));
     const int j0 = jb * NB;
     double* Ajj[2] = {nullptr, nullptr};
     double* Li[2] = {nullptr, nullptr};
     double* Pl[2] = {nullptr, nullptr};
     int64_t lda[2] = {0, 0};
     int nbj[2] = {0, 0};
-    GemmCall panel[2], trail[2];
+    GemmCall panel[2], trail[2], next[2], rest[2];
+    bool any_rest = false;
     for (int q = 0; q < nsys; ++q) {
       const CholSys& y = sys[q];
       if (j0 >= y.m) continue;
@@ -590,6 +618,17 @@ int cholesky_aug_pair_async(nk_ctx* ctx, const CholSys* sys, int nsys, hipEvent_
           trail[q].A = pnl; trail[q].lda = y.ldp; trail[q].B = pnl; trail[q].ldb = y.ldp;
           trail[q].C = y.P + (int64_t)(j0 + nbj[q]) * y.ldp + (j0 + nbj[q]); trail[q].ldc = y.ldp;
           trail[q].opts.tri = TRI_LOWER;  // lower tiles of the square part, full tiles for the extra rows
+          // split for the look-ahead: the next block column (all rows) | everything to the right of it
+          const int nbn = rem < NB ? rem : NB;
+          next[q] = trail[q];
+          next[q].N = nbn;
+          if (rem > nbn) {
+            rest[q] = trail[q];
+            rest[q].M = rows - nbn; rest[q].N = rem - nbn;
+            rest[q].A = rest[q].B = pnl + (int64_t)nbn * y.ldp;
+            rest[q].C = trail[q].C + (int64_t)nbn * y.ldp + nbn;
+            any_rest = true;
+          }
         }
       }
     }
@@ -599,13 +638,32 @@ int cholesky_aug_pair_async(nk_ctx* ctx, const CholSys* sys, int nsys, hipEvent_
       if (!launch_chol_panel_pair(ctx, panel, nsys, &rc_panel)) NK_TRY(launch_gemm_pair(ctx, false, true, panel, nsys));
       NK_TRY(rc_panel);
     }
-    {
-      int rc_trail = NK_OK;  // K = 64 rank update: specialised kernel (nk_trail.hip), generic engine otherwise
-      if (!launch_chol_trail_pair(ctx, trail, nsys, &rc_trail)) NK_TRY(launch_gemm_pair(ctx, false, true, trail, nsys));
-      NK_TRY(rc_trail);
+    auto update = [&](const GemmCall* calls) -> int {  // K = 64 rank update: specialised kernel, generic engine otherwise
+      int rc_trail = NK_OK;
+      if (!launch_chol_trail_pair(ctx, calls, nsys, &rc_trail)) NK_TRY(launch_gemm_pair(ctx, false, true, calls, nsys));
+      return rc_trail;
+    };
+    if (!lookahead) {
+      NK_TRY(update(trail));
+    } else {
+      hipEvent_t evP = ev[jb & 1], evR = ev[2 + (jb & 1)], evR_prev = ev[2 + ((jb + 1) & 1)];
+      NK_HIP(hipEventRecord(evP, s_chain));                               // panel(jb) is complete
+      if (rest_pending) NK_HIP(hipStreamWaitEvent(s_chain, evR_prev, 0));  // the next column has its older updates
+      NK_TRY(update(next));
+      rest_pending = false;
+      if (any_rest) {
+        ctx->stream = s_rest;
+        NK_HIP(hipStreamWaitEvent(s_rest, evP, 0));
+        const int rc = update(rest);
+        if (rc == NK_OK) NK_HIP(hipEventRecord(evR, s_rest));
+        last_rest = evR;
+        ctx->stream = s_chain;
+        NK_TRY(rc);
+        rest_pending = true;
+      }
     }
-    if (mark != nullptr && (jb == mark_step || (jb == nblk - 1 && mark_step >= nblk))) NK_HIP(hipEventRecord(mark, ctx->stream));
   }
+  if (lookahead && last_rest) NK_HIP(hipStreamWaitEvent(s_chain, last_rest, 0));  // (the chain also ends behind the last rest)
   // backward on the extra rows E (extra x m, now holding (L^-1 R)^T):  E <- E L^-1, one launch (nk_trsm.hip)
   NK_TRY(launch_trsm_right_lower_pair(ctx, sys, nsys));
   return NK_OK;
@@ -740,7 +798,7 @@ int sqrtm_prepare(nk_ctx* ctx, const double* P, int64_t ldp, int m, SqrtPlan* pl
   NK_TRY(launch_add_diag(ctx, E, m, m, 1.0));
   CholSys y;
   y.P = plan->W; y.ldp = m; y.m = m; y.extra = m; y.backward = false; y.Linv = plan->Linv;
-  NK_TRY(cholesky_aug_pair_async(ctx, &y, 1));  // W <- [L ; L^-T]
+  NK_TRY(cholesky_aug_pair_async(ctx, &y, 1, plan->pause_event, plan->pause_step));  // W <- [L ; L^-T]
   {
     // ||L^-1||_F^2 (the extra rows hold L^-T): 1 / it bounds the smallest eigenvalue of P from below
     const ArenaMark mk = arena_mark(ctx);

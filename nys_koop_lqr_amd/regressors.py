@@ -126,6 +126,11 @@ class KoopmanNystromRegressor(KoopmanRegressor):
     B = _fetched("B")
     C = _fetched("C")
     weights = _fetched("weights")
+    # Arithmetic of the O(n m d) kernel blocks and O(n m^2) Gram contractions of `fit`: "f64" (the only mode that meets the
+    # 1e-6 operator bar) or "f32" (BASELINE.json's stress configuration; include/nyskoop.h, nk_set_compute_dtype).  An
+    # attribute, not a constructor argument: the constructor mirrors the reference's (sklearn clone / get_params), and a
+    # clone starts from the default.
+    compute_dtype = "f64"
 
     def __init__(self, n_inputs, kernel=None, gamma=None, m=None):
         self._fetching = False
@@ -304,9 +309,14 @@ class KoopmanNystromRegressor(KoopmanRegressor):
         self._drop_model()
         t_host1 = time.perf_counter()
         ctx.wait_for(X, Y)  # device tensors: whatever torch still has queued for them comes first
-        rc = ctx.lib.nk_nystrom_fit(ctx.handle, C.byref(kd), Xm.ptr, Xm.ld, Ym.ptr, Ym.ld, n, d, p, rr, n_rr,
-                                    None if same else Zi.ctypes.data, d, Zo.ctypes.data, d, m,
-                                    float(self.gamma), float(self.jitter), C.byref(h), C.byref(stats))
+        ctx.set_compute_dtype(self.compute_dtype)
+        try:
+            rc = ctx.lib.nk_nystrom_fit(ctx.handle, C.byref(kd), Xm.ptr, Xm.ld, Ym.ptr, Ym.ld, n, d, p, rr, n_rr,
+                                        None if same else Zi.ctypes.data, d, Zo.ctypes.data, d, m,
+                                        float(self.gamma), float(self.jitter), C.byref(h), C.byref(stats))
+        finally:
+            if self.compute_dtype != "f64":
+                ctx.set_compute_dtype("f64")
         self._raise(ctx, rc)
         self._adopt(ctx, h, stats, m, d, p, (t_host0, t_host1), fetch)
 

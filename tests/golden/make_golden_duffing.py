@@ -83,6 +83,30 @@ def dlqr(A, B, Q, R_):
     return np.linalg.solve(B.T @ P @ B + R_, B.T @ P @ A)
 
 
+def closed_loop(ds, reg, x0, reference, steps):
+    """benchmark_lqr_classic.py:256-299 for one fitted regressor: K = dlqr(A, B, C^T C, I), lqr_control (:67-89, plant in the
+    loop, a lift per step), open_loop_control (:91-97)."""
+    K = dlqr(reg.A, reg.B, reg.C.T @ reg.C, np.eye(1))
+    phi_new, phi_ref = reg.lift(x0), reg.lift(reference)
+    visited, u_s, x_new = x0, np.empty((1, 0)), x0
+    for _ in range(steps):
+        u_op = K @ (phi_ref - phi_new)
+        u_s = np.hstack((u_s, u_op.reshape(1, 1)))
+        visited = np.hstack((visited, reg.C @ phi_new))
+        x_new = ds.update_SOM(x_new, u_op)
+        phi_new = reg.lift(x_new)
+    state, states = x0, x0.reshape([-1, 1])
+    for i in range(u_s.shape[1]):
+        state = ds.update_SOM(state, u_s[:, i])
+        states = np.hstack((states, state))
+    return K, visited, u_s, states
+
+
+def duffing_plant():
+    return DS.DuffingOscillator(Ts=0.01, name="duffing", n_states=2, n_inputs=1, radius_sampling=1.0, angle_sampling=2,
+                                input_lb=[-1], input_ub=[1])
+
+
 class ChoiceSpy:
     """Observes np.random.choice (regressors.py:130) to record the landmark indices the reference drew."""
 
@@ -166,25 +190,20 @@ def main():
         with ChoiceSpy() as spy:
             reg = R.KoopmanNystromRegressor(1, kernel=R.KernelWrapper([1, 1]), gamma=gamma, m=20)
             reg.fit(X.T, Y.T)
-        K = dlqr(reg.A, reg.B, reg.C.T @ reg.C, np.eye(1))
-        # lqr_control (:67-89)
-        phi_new, phi_ref = reg.lift(x0), reg.lift(reference)
-        visited, u_s, x_new = x0, np.empty((1, 0)), x0
-        for _ in range(steps):
-            u_op = K @ (phi_ref - phi_new)
-            u_s = np.hstack((u_s, u_op.reshape(1, 1)))
-            visited = np.hstack((visited, reg.C @ phi_new))
-            x_new = ds.update_SOM(x_new, u_op)
-            phi_new = reg.lift(x_new)
-        # open_loop_control (:91-97)
-        state, states = x0, x0.reshape([-1, 1])
-        for i in range(u_s.shape[1]):
-            state = ds.update_SOM(state, u_s[:, i])
-            states = np.hstack((states, state))
+        K, visited, u_s, states = closed_loop(ds, reg, x0, reference, steps)
+        # the reference's own reproducibility of the whole chain (fit -> DARE -> 2000 feedback steps): same landmarks,
+        # inputs perturbed by 1e-15
+        reg2 = R.KoopmanNystromRegressor(1, kernel=R.KernelWrapper([1, 1]), gamma=gamma, m=20)
+        reg2.nystrom_centers_output = Y[:, spy.draws[-1]]
+        reg2.fit(Xp.T, Y.T)
+        K2, _, u2, st2 = closed_loop(ds, reg2, x0, reference, steps)
+        out[f"lqr_sens_{seed}"] = np.array([max(relf(reg2.A, reg.A), relf(reg2.B, reg.B), relf(reg2.C, reg.C)),
+                                            relf(K2, K), relf(u2, u_s), relf(st2, states)])
         out[f"lqr_idx_{seed}"], out[f"lqr_K_{seed}"] = spy.draws[-1], K
         out[f"lqr_A_{seed}"], out[f"lqr_B_{seed}"], out[f"lqr_C_{seed}"] = reg.A, reg.B, reg.C
         out[f"lqr_visited_{seed}"], out[f"lqr_us_{seed}"], out[f"lqr_states_{seed}"] = visited, u_s, states
-        print(f"lqr seed {seed}: final state {states[:, -1]}, |u| max {np.abs(u_s).max():.3f}", flush=True)
+        print(f"lqr seed {seed}: final state {states[:, -1]}, |u| max {np.abs(u_s).max():.3f}; the 1e-15 perturbation moves "
+              f"(operators, K, controls, states) by {out[f'lqr_sens_{seed}']}", flush=True)
     out["lqr_steps"] = steps
     np.savez_compressed(f"{OUT}/f12_duffing_full.npz", **out)
     print("wrote f12_duffing_full.npz", os.path.getsize(f"{OUT}/f12_duffing_full.npz") / 1e6, "MB")

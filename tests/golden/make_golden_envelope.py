@@ -110,6 +110,8 @@ def duffing():
     X, Y, ms = g["X"], g["Y"], g["ms"]
     ref = g["ref_rmse"]
     dev = {}
+    op_dev = {10: 0.0, 48: 0.0, 200: 0.0}  # operators of (seed 0, m): largest deviation of A, B, C over the drivers
+    relf = lambda a, b: float(np.linalg.norm(a - b) / np.linalg.norm(b))
     t0 = time.time()
     for mode in ("gelsy", "chol", "eigh"):
         rm = np.zeros_like(ref)
@@ -120,10 +122,31 @@ def duffing():
                     reg.nystrom_centers_output = Y.T[:, g[f"idx_{seed}_{k}"]]
                     reg.fit(X, Y)
                     rm[si, k] = MD.validate_dyn_sys(reg, g[f"traj_{seed}"], g[f"ctrl_{seed}"])[0]
+                    if seed == 0 and int(m) in op_dev:
+                        op_dev[int(m)] = max(op_dev[int(m)], relf(reg.A, g[f"A_m{m}"]), relf(reg.B, g[f"B_m{m}"]),
+                                             relf(reg.C, g[f"C_m{m}"]))
         dev[mode] = np.abs(rm - ref) / ref
         print(f"duffing: {mode} done (%.0f s), max deviation from gelsd %.2e" % (time.time() - t0, dev[mode].max()), flush=True)
+    # the LQR chain of benchmark_lqr_classic.py:256-299 (m = 20) through the other drivers
+    ds = MD.duffing_plant()
+    x0, reference, steps = np.array([-0.5, 0.0]).reshape([-1, 1]), np.zeros((2, 1)), int(g["lqr_steps"])
+    lqr_env = {int(seed): np.zeros(4) for seed in g["seeds"]}
+    for mode in ("gelsy", "chol", "eigh"):
+        with LstsqSwap(mode):
+            for seed in g["seeds"]:
+                reg = R.KoopmanNystromRegressor(1, kernel=R.KernelWrapper([1, 1]), gamma=float(g["gamma"]), m=20)
+                reg.nystrom_centers_output = Y.T[:, g[f"lqr_idx_{seed}"]]
+                reg.fit(X, Y)
+                K, _, us, st = MD.closed_loop(ds, reg, x0, reference, steps)
+                d4 = np.array([max(relf(reg.A, g[f"lqr_A_{seed}"]), relf(reg.B, g[f"lqr_B_{seed}"]), relf(reg.C, g[f"lqr_C_{seed}"])),
+                               relf(K, g[f"lqr_K_{seed}"]), relf(us, g[f"lqr_us_{seed}"]), relf(st, g[f"lqr_states_{seed}"])])
+                lqr_env[int(seed)] = np.maximum(lqr_env[int(seed)], d4)
+    print("duffing LQR envelope (operators, K, controls, states) by seed:", lqr_env, flush=True)
     env = np.max(np.stack(list(dev.values())), axis=0)
-    np.savez_compressed(f"{OUT}/f12b_duffing_envelope.npz", envelope=env, **{f"dev_{k}": v for k, v in dev.items()})
+    print("duffing operator envelope (seed 0):", op_dev)
+    np.savez_compressed(f"{OUT}/f12b_duffing_envelope.npz", envelope=env, op_envelope_m=np.array(sorted(op_dev)),
+                        op_envelope=np.array([op_dev[k] for k in sorted(op_dev)]),
+                        **{f"lqr_envelope_{k}": v for k, v in lqr_env.items()}, **{f"dev_{k}": v for k, v in dev.items()})
     print("duffing envelope by m (max over seeds):", dict(zip(ms.tolist(), np.round(env.max(axis=0), 6).tolist())))
 
 

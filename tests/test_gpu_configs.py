@@ -185,6 +185,31 @@ def test_c5_scaled_twin_vs_reference(nk, golden):
     assert errs["forecast20"] < 1e-5
 
 
+def test_c5_scaled_twin_fp32_engine(nk, golden):
+    """BASELINE.json configs[4] names fp32 for the stress configuration.  The fp32 engine (kernel blocks and Gram
+    contractions on the fp32 matrix pipe; Gram accumulators and everything m x m in fp64) on the same twin, against the
+    same reference outputs: fp32 cannot reach the 1e-6 operator bar of the fp64 path -- what it does
+    reach on operators is printed, and the quantities the stress configuration is graded on (predictions, the 20-step
+    forecast) are asserted."""
+    g = golden("f11_c5_twin.npz")
+    n, d, p, m = int(g["n"]), int(g["d"]), int(g["p"]), int(g["m"])
+    X, Y, rng = _c5_like(n, d, p, int(g["seed"]))
+    ls, gamma = float(g["ls"]), float(g["gamma"])
+    reg = nk.KoopmanNystromRegressor(p, kernel=nk.ThreeDimensionalKernel(ls, ls, ls, d), gamma=gamma, m=m)
+    reg.compute_dtype = "f32"
+    reg.nystrom_centers_output = np.ascontiguousarray(Y.T[:, g["idx"]])
+    reg.fit(X, Y)
+    st = reg.fit_stats_
+    prng = np.random.default_rng(int(g["probe_seed"]))
+    PA = prng.standard_normal((m, 16))
+    PC = prng.standard_normal((m, 16))
+    errs = dict(A=relf(reg.A @ PA, g["A_probe"]), At=relf(reg.A.T @ PA, g["At_probe"]), C=relf(reg.C @ PC, g["C_probe"]),
+                B=relf(reg.B, g["B"]), predict=relf(reg.predict(X[g["q"]]), g["predict"]))
+    errs["forecast20"] = relf(reg.rollout(X[int(g["x0_row"]), :d], g["Useq"]), g["forecast"])
+    print("\n[C5 twin, fp32 engine] errors vs reference:", errs, "| kmat %.2f ms, gram %.2f ms" % (st["ms_kmat"], st["ms_gram"]))
+    assert errs["predict"] < 1e-3 and errs["forecast20"] < 1e-2
+
+
 @pytest.mark.timeout(900)
 def test_c5_full_size_properties(nk):
     """n = 1e6, m = 8000, d = 1024, p = 6, fp64 end to end, inputs generated on the device (torch is plumbing: device
@@ -341,12 +366,15 @@ def test_duffing_full_shape_open_loop_sweep_vs_reference(nk, golden):
 
 @pytest.mark.parametrize("m", [10, 48, 200])
 def test_duffing_full_shape_operators_vs_reference(nk, golden, m):
-    """Operators of (seed 0, m) at n = 69 900 against the reference's; bar = 10 x the movement of the reference's own
-    operators under the 1e-15 input perturbation (floor 1e-9)."""
+    """Operators of (seed 0, m) at n = 69 900 against the reference's; bar = max(10 x the movement of the reference's own
+    operators under the 1e-15 input perturbation, 1.5 x their movement when the reference's two solves go through
+    another LAPACK driver (make_golden_envelope.py), 1e-9)."""
     g = golden("f12_duffing_full.npz")
+    e = golden("f12b_duffing_envelope.npz")
     k = int(np.where(g["ms"] == m)[0][0])
     reg = _duffing_fit(nk, g, g[f"idx_0_{k}"], m)
-    bar = max(10.0 * float(g["op_sensitivity"][0, k]), 1e-9)
+    op_env = float(e["op_envelope"][int(np.where(e["op_envelope_m"] == m)[0][0])])
+    bar = max(10.0 * float(g["op_sensitivity"][0, k]), 1.5 * op_env, 1e-9)
     errs = dict(A=relf(reg.A, g[f"A_m{m}"]), B=relf(reg.B, g[f"B_m{m}"]), C=relf(reg.C, g[f"C_m{m}"]))
     print(f"\nduffing n=69900 m={m}: {errs}, bar {bar:.2e} (reference moves {float(g['op_sensitivity'][0, k]):.2e})")
     assert max(errs.values()) <= bar, (errs, bar)
@@ -356,10 +384,13 @@ def test_duffing_plant_in_the_loop_lqr_vs_reference(nk, O, golden):
     """benchmark_lqr_classic.py:256-299: m = 20 fit on the full data set, K = dlqr(A, B, C^T C, I), 2000 steps of u = K (phi(0)
     - phi(x)) with the PLANT in the loop (a lift per step) and the open-loop replay of the controls (:91-97), seeds 0..2,
     against the reference's own run (plant = the oracle's restatement of dynamical_systems.py:25-48; test infrastructure).
-    The loop feeds its own state back 2000 times, so the bar is on the trajectory as a whole."""
+    Bars, per seed and per quantity: max(10 x what the reference's own chain (fit -> DARE -> 2000 feedback steps) moves by
+    when its inputs are perturbed by 1e-15 (`lqr_sens`), 1.5 x what it moves by when its two solves go through another
+    LAPACK driver (`lqr_envelope`, make_golden_envelope.py), 1e-8)."""
     from nys_koop_lqr_amd import harness
     from nys_koop_lqr_amd.lqr import dlqr
     g = golden("f12_duffing_full.npz")
+    env = golden("f12b_duffing_envelope.npz")
     steps = int(g["lqr_steps"])
     plant = lambda x, u: O.duffing_step(x, u, 0.01)
     x0, ref0 = np.array([[-0.5], [0.0]]), np.zeros((2, 1))
@@ -375,4 +406,6 @@ def test_duffing_plant_in_the_loop_lqr_vs_reference(nk, O, golden):
         e_u, e_x = relf(us, g[f"lqr_us_{seed}"]), relf(states, g[f"lqr_states_{seed}"])
         print(f"\nduffing LQR seed {seed}: operators {e_ops:.2e}, K {e_K:.2e}, controls {e_u:.2e}, states {e_x:.2e} "
               f"({steps} plant-in-the-loop steps in {dt:.2f} s)")
-        assert e_ops < 1e-6 and e_K < 1e-5 and e_u < 1e-4 and e_x < 1e-4
+        bars = np.maximum(np.maximum(10.0 * g[f"lqr_sens_{seed}"], 1.5 * env[f"lqr_envelope_{seed}"]), 1e-8)
+        print("   bars:", bars)
+        assert e_ops <= bars[0] and e_K <= bars[1] and e_u <= bars[2] and e_x <= bars[3]

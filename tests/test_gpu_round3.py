@@ -88,3 +88,51 @@ def test_tn_engine_products_vs_numpy(nk, M, N, K):
     _lib.check(ctx.lib.nk_gemm(ctx.handle, 1, 0, M, N, K, 1.0, A.ctypes.data, M, B.ctypes.data, N, 0.0, C.ctypes.data, N))
     ref = A.T @ B
     assert relf(C, ref) < 5e-15
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (2006, 2000, 4100), (384, 2000, 777), (132, 260, 33), (4, 4, 5)])
+def test_fp32_engine_gram_products_vs_numpy(nk, M, N, K):
+    """C (fp64) = A^T B with fp32 operands through the fp32 engine's Gram entry (nk_bench-free path: a fit-shaped call is
+    not needed, the engine is reachable through nk_gemm_f32): products of fp32 numbers accumulated in fp32 for at most
+    1024 rows at a time, then in fp64 -- compared with the fp64 product of the same rounded operands."""
+    from nys_koop_lqr_amd import _lib
+    rng = np.random.default_rng(M + 3 * N + 11 * K)
+    A = rng.standard_normal((K, M)).astype(np.float32)
+    B = rng.standard_normal((K, N)).astype(np.float32)
+    lda, ldb = (M + 3) & ~3, (N + 3) & ~3
+    Ap = np.zeros((K, lda), dtype=np.float32); Ap[:, :M] = A
+    Bp = np.zeros((K, ldb), dtype=np.float32); Bp[:, :N] = B
+    ctx = nk.get_context()
+    C = np.empty((M, N))
+    _lib.check(ctx.lib.nk_gemm_f32(ctx.handle, M, N, K, Ap.ctypes.data, lda, Bp.ctypes.data, ldb, C.ctypes.data, N))
+    ref = A.astype(np.float64).T @ B.astype(np.float64)
+    err = np.abs(C - ref).max() / np.abs(ref).max()
+    assert err < 2e-6, err
+
+
+def test_cholesky_lookahead_gives_the_same_bits(nk, monkeypatch):
+    """The blocked Cholesky with look-ahead (next block column on the chain's stream, the rest of the trailing update on a
+    second stream) performs exactly the arithmetic of the sequential order: a fit with it computes the same bits as a fit
+    without (NYSKOOP_CHOL_LOOKAHEAD=0 is read once per process, so the two fits run in child processes)."""
+    code = r'''
+import numpy as np, sys, hashlib
+sys.path.insert(0, %r)
+import nys_koop_lqr_amd as nk
+rng = np.random.default_rng(8)
+n, d, p, m = 3000, 40, 3, 700
+S = rng.standard_normal((n, d)); U = rng.standard_normal((n, p))
+Y = np.tanh(S @ (rng.standard_normal((d, d)) * 0.9 / np.sqrt(d))) + U @ (rng.standard_normal((p, d)) * 0.1)
+X = np.hstack([S, U])
+reg = nk.KoopmanNystromRegressor(p, kernel=nk.ThreeDimensionalKernel(6., 6., 6., d), gamma=1e-5, m=m)
+reg.nystrom_centers_output = np.ascontiguousarray(Y[:m].T)
+reg.fit(X, Y)
+h = hashlib.sha256(np.ascontiguousarray(reg.A).tobytes() + np.ascontiguousarray(reg.B).tobytes() + np.ascontiguousarray(reg.C).tobytes()).hexdigest()
+print("HASH", h)
+''' % ROOT
+    hashes = []
+    for la in ("1", "0"):  # (off by default: nk_linalg.hip)
+        env = dict(os.environ, NYSKOOP_CHOL_LOOKAHEAD=la)
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+        assert out.returncode == 0, (out.stdout[-300:], out.stderr[-1500:])
+        hashes.append([l for l in out.stdout.splitlines() if l.startswith("HASH")][0])
+    assert hashes[0] == hashes[1]

@@ -85,25 +85,55 @@ def main():
         g = {8: r[0:2], 9: r[2:4], 10: r[4:6], 11: r[6:8]}
         block(1, g, pre=["s_waitcnt lgkmcnt(0)"], mid=(8, ["s_waitcnt vmcnt(0)", "s_barrier"]))
 
-    lines += ["s_mov_b64 s[92:93], %[rowa]", "s_mov_b64 s[94:95], %[rowb]", "nk_tn_loop_%=:"]
-    step(0)
-    step(1)
-    lines += ["s_sub_u32 %[cnt], %[cnt], 1", "s_cmp_lg_u32 %[cnt], 0", "s_cbranch_scc1 nk_tn_loop_%="]
+    def last(st):
+        """the final step of a K range whose last step is a full one: no DMA, no barrier, nothing fetched for a next step"""
+        r = reads(1, 1, st)
+        block(0, {n: [r[n]] for n in range(8)}, pre=["s_waitcnt lgkmcnt(0)"])
+        r = reads(2, 0, st)
+        block(1, {n: [r[n]] for n in range(8)}, pre=["s_waitcnt lgkmcnt(0)"])
+        r = reads(3, 1, st)
+        block(0, {n: [r[n]] for n in range(8)}, pre=["s_waitcnt lgkmcnt(0)"])
+        block(1, {}, pre=["s_waitcnt lgkmcnt(0)"])
+
+    def emit(name, body, counts):
+        nonlocal lines
+        lines = []
+        body()
+        print(f"#define {name} \\")
+        for ln in lines:
+            print(f'  "{ln}\\n\\t" \\')
+        print('  ""')
+        nm = sum(1 for ln in lines if ln.startswith("v_mfma"))
+        nr = sum(1 for ln in lines if ln.startswith("ds_read"))
+        nd = sum(1 for ln in lines if ln.startswith("global_load_lds"))
+        assert (nm, nr, nd) == counts, (name, nm, nr, nd)
+
+    def whole():
+        """every full step of a K range in ONE block (one register allocation for the compiler to respect): cnt trips of two
+        steady steps, then -- by the bits of `flags` -- one more steady step (bit 0) and the final step (bit 1)"""
+        lines.extend(["s_mov_b64 s[92:93], %[rowa]", "s_mov_b64 s[94:95], %[rowb]",
+                      "s_cmp_eq_u32 %[cnt], 0", "s_cbranch_scc1 nk_tn_after_%=", "nk_tn_loop_%=:"])
+        step(0)
+        step(1)
+        lines.extend(["s_sub_u32 %[cnt], %[cnt], 1", "s_cmp_lg_u32 %[cnt], 0", "s_cbranch_scc1 nk_tn_loop_%=",
+                      "nk_tn_after_%=:", "s_bitcmp1_b32 %[flags], 0", "s_cbranch_scc0 nk_tn_even_%="])
+        step(0)
+        lines.extend(["s_bitcmp1_b32 %[flags], 1", "s_cbranch_scc0 nk_tn_end_%="])
+        last(1)
+        lines.extend(["s_branch nk_tn_end_%=", "nk_tn_even_%=:", "s_bitcmp1_b32 %[flags], 1", "s_cbranch_scc0 nk_tn_end_%="])
+        last(0)
+        lines.append("nk_tn_end_%=:")
+
     print("// GENERATED by tools/gen_tn_kstep.py -- do not edit by hand.")
-    print("// The steady-state k loop of the 128 x 128 fp64 tile, TWO k-steps (LDS stage 0, then 1) per trip, cnt trips.")
+    print("// k-steps (16 contraction rows each) of the 128 x 128 fp64 tile, every non-matrix instruction in a gap between two MFMAs.")
     print("// Operands: c00..c33 (+v, 8 VGPRs each: the accumulators); a00..a03 b00..b03 (+v: register set 0, holds sub-step 0 of")
     print("// the current step on entry and of the next unprocessed step on exit); a10..b13 (=&v: scratch set); ard0/brd0, ard1/brd1")
     print("// (v: LDS read addresses of the fragments in stage 0 / 1); voa/vob (v: per-lane byte offsets of the DMA); rowa/rowb")
     print("// (s, 64 bit: this wave's first row of the step AFTER the current one); stra/strb (s: 4 rows in bytes); dst0/dst1 (s:")
-    print("// LDS byte address of this wave's first DMA row in stage 0 / 1); cnt (+s: trips, >= 1).  Clobbers s[92:95], m0, scc.")
-    print("#define NK_TN_KLOOP_ASM \\")
-    for ln in lines:
-        print(f'  "{ln}\\n\\t" \\')
-    print('  ""')
-    nm = sum(1 for ln in lines if ln.startswith("v_mfma"))
-    nr = sum(1 for ln in lines if ln.startswith("ds_read"))
-    nd = sum(1 for ln in lines if ln.startswith("global_load_lds"))
-    assert (nm, nr, nd) == (128, 64, 16), (nm, nr, nd)
+    print("// LDS byte address of this wave's first DMA row in stage 0 / 1).  Clobbers s[92:95], m0, scc.")
+    print("// NK_TN_KSTEPS_ASM: cnt (+s) trips of TWO steady steps (LDS stage 0, then 1); then, if bit 0 of flags (s) is set, ONE more")
+    print("// steady step (stage 0); then, if bit 1 is set, the final step of the K range (no DMA, no barrier) on the stage that follows.")
+    emit("NK_TN_KSTEPS_ASM", whole, (64 * 5, 32 * 3 + 24 * 2, 8 * 3))
 
 
 if __name__ == "__main__":
