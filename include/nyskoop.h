@@ -104,7 +104,7 @@ int nk_set_strict_spd(nk_ctx* ctx, int strict);
  * (regressors.py:141-142,151,153,162,164).  NK_DTYPE_F64 (default): fp64 end to end, the only mode that meets the 1e-6
  * operator bar.  NK_DTYPE_F32 (the stress configuration of BASELINE.json: n = 1e6, m = 8000, d = 1024, "fp32"): rows and
  * kernel values are rounded to fp32 and multiplied on the fp32 matrix pipe (twice the fp64 rate, half the bytes); the
- * Gram accumulators are kept in fp64 (fp32 partial sums never run over more than 1024 rows) and everything m x m --
+ * Gram accumulators are kept in fp64 (fp32 partial sums never run over more than 32 rows) and everything m x m --
  * regularised solves, square root, operators, lift, predict, rollouts -- stays fp64.  Needs d >= 32 and shared input /
  * output landmarks; contexts of a lock-step group ignore it. */
 #define NK_DTYPE_F64 0
@@ -159,8 +159,10 @@ int nk_group_stats(nk_ctx* member, uint64_t* out4);
  *   out[1] single-launch Jacobi sweeps (rank-truncating branch of the fit inside a lock-step group) that gave up the
  *          same way and finished with one launch per round;
  *   out[2] fits whose regularised system(s) took the rank-truncating branch (regressors.py:155,165: lstsq / gelsd);
- *   out[3] fits that repeated the matrix square root with the factorisation-free iteration.
- * n = number of entries the caller provides (<= 4 are written). */
+ *   out[3] fits that repeated the matrix square root with the factorisation-free iteration;
+ *   out[4] regularised systems without a spectral gap (pivots decaying through the rounding level) that were solved at
+ *          full rank after a minimal diagonal shift instead of going through the SVD.
+ * n = number of entries the caller provides (<= 5 are written). */
 int nk_runtime_counters(uint64_t* out, int32_t n);
 /* Releases everything the library still holds on every device -- live contexts (their streams, events and workspaces),
  * live models, the model-buffer pool and page-locked host blocks -- after waiting for pending work.  Handles that were
@@ -277,7 +279,7 @@ int nk_linear_rollout(nk_ctx* ctx, const double* A, const double* B, const doubl
 /* ---- building blocks exported for parity tests and reuse (device or host pointers) --------------------- */
 /* C[M x N] = alpha * op(A) op(B) + beta * C;  transA: A is stored K x M;  transB: B is stored N x K. */
 /* C[M x N] (fp64) = A^T B with fp32 operands stored K x M / K x N (the fp32 engine of nk_set_compute_dtype as a building
- * block: fp32 products, fp32 partial sums over at most 1024 rows, fp64 beyond).  Operands 16-byte aligned, lda / ldb
+ * block: fp32 products, fp32 partial sums over at most 32 rows, fp64 beyond).  Operands 16-byte aligned, lda / ldb
  * multiples of 4, M, N >= 4. */
 int nk_gemm_f32(nk_ctx* ctx, int64_t M, int64_t N, int64_t K, const float* A, int64_t lda, const float* B, int64_t ldb,
                 double* C, int64_t ldc);

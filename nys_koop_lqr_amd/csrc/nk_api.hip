@@ -410,6 +410,7 @@ int nk_create(int device, nk_ctx** out) {
   ctx->cur_arena = &ctx->arena;
   NK_HIP(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
   NK_HIP(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+  NK_HIP(hipEventCreateWithFlags(&ctx->ev_chain, hipEventDisableTiming));
   NK_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->d_info), 256));
   ctx->d_piv = reinterpret_cast<unsigned long long*>(ctx->d_info + 16);  // 8 x 8 bytes behind the 4 flag slots
   NK_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->d_scalars), 64 * sizeof(double)));
@@ -447,6 +448,7 @@ static void destroy_ctx_unregistered(nk_ctx* ctx) {
   for (auto& c : ctx->arena_side.chunks) (void)hipFree(c.base);
   (void)hipEventDestroy(ctx->ev_fork);
   (void)hipEventDestroy(ctx->ev_join);
+  if (ctx->ev_chain) (void)hipEventDestroy(ctx->ev_chain);
   if (ctx->ev_ext) (void)hipEventDestroy(ctx->ev_ext);
   for (int i = 0; i < 8; ++i) if (ctx->ev_up[i]) (void)hipEventDestroy(ctx->ev_up[i]);
   (void)hipStreamDestroy(ctx->stream_side);
@@ -1072,6 +1074,7 @@ static int fit_impl(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int6
       NK_TRY(launch_gemm_tn_f32_multi(ctx, pf, 4, o32, 0, timed ? &ms1 : nullptr, multi_pass));
       if (multi_pass) ms_gram_kernel += ms1; else gram_deferred = timed;
       gram_launches += 1;
+      if (pipelined && ip + 1 < passes.size()) NK_TRY(upload_pass(ip + 1));
       continue;
     }
     // -- kernel blocks of this pass
@@ -1196,12 +1199,12 @@ static int fit_impl(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int6
     // This chain of ~100 small high-priority kernels must not run beside the fused Gram launch: that launch fills the
     // chip in exact rounds of 3-ms workgroups, and a Gram workgroup whose slot a chain kernel holds at a round boundary
     // finds the next free slot a whole round later -- measured: the launch takes 26.5-27.0 ms inside the fit against 25.0
-    // alone.  So the chain runs its first steps beside the kernel blocks (short workgroups: a displaced one waits
-    // microseconds), pauses, and finishes after the Gram launch -- ahead of the square-root iteration, which has that
-    // much slack against the factorisation chain of the regularised systems.  NYSKOOP_PREP_PAUSE = fraction of the
-    // block steps to run before the pause (default 0.5; 1 = never pause).
+    // alone.  So the chain waits for the Gram launch and runs after it -- ahead of the square-root iteration, which has
+    // that much slack against the factorisation chain of the regularised systems.  NYSKOOP_PREP_PAUSE = fraction of the
+    // block steps to run BEFORE the pause, beside the kernel blocks (1 = never pause).  Measured on one box, ms per fit:
+    // 1 -> 44.1, 0.75 -> 44.1, 0.5 -> 43.2, 0.25 -> 43.2, 0 (default) -> 42.9 (kernel blocks 6.9 -> 6.3, Gram 26.7 -> 25.5).
     if (mode == FIT_FULL && n_eff >= 20000 && m >= 1024) {
-      static const double frac = getenv("NYSKOOP_PREP_PAUSE") ? atof(getenv("NYSKOOP_PREP_PAUSE")) : 0.5;
+      static const double frac = getenv("NYSKOOP_PREP_PAUSE") ? atof(getenv("NYSKOOP_PREP_PAUSE")) : 0.0;
       const int nb = (m + CHOL_NB - 1) / CHOL_NB;
       if (frac < 1.0) {
         splan.pause_event = ctx->ev_fork;  // recorded above, behind the last Gram launch
@@ -1246,6 +1249,8 @@ static int fit_impl(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int6
   // both systems advance in lock step (paired launches); the per-block kernels are latency bound and leave the chip
   // mostly idle ...
   NK_TRY(cholesky_aug_pair_async(ctx, sys, 2));  // G2 <- cross inner^-1 (m x mp) ; G4 <- left_rec inner_rec^-1 (d x m)
+  // (tried: holding the GEMM-bound iteration back until this latency-bound chain is done -- 43.3 against 42.7 ms per fit;
+  // with look-ahead in both chains 43.7 / 47.5: the overlap of the two, slow as each becomes, is still the best schedule)
   tr.mark("cholesky + solves issued");
 
   // ---- ... while S = K_mm^{1/2}, S^{-1} (regressors.py:140,163) runs on the side stream (GEMM bound) --------------------
@@ -1300,8 +1305,8 @@ static int fit_impl(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int6
   NK_TRY(operator_products());
   NK_HIP(hipEventRecord(ev[5], ctx->stream));
   tr.mark("solve issued");
-  int chol_failed[2] = {0, 0};
-  NK_TRY(cholesky_fail_flags(ctx, sys, 2, chol_failed));  // synchronises the main stream (which has joined the side stream)
+  int chol_failed[2] = {0, 0}, chol_kind[2] = {0, 0};
+  NK_TRY(cholesky_fail_flags(ctx, sys, 2, chol_failed, chol_kind));  // synchronises the main stream (which has joined the side stream)
   tr.mark("final sync");
   int rank_sys[2] = {mp, m};
   bool redo_products = false;
@@ -1311,11 +1316,42 @@ static int fit_impl(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int6
                 "lstsq truncates here) and strict mode is on", chol_failed[0] ? 0 : 1);
       return NK_ERR_NOT_SPD;
     }
-    // numerically rank-deficient system(s): lstsq's (gelsd's) minimum-norm solution, singular values <= eps * sigma_max
-    // dropped (nk_pinv.hip)
+    // Numerically rank-deficient system(s).  Two classes (CHOL_FAIL_*, nk_linalg.hip):
+    //  * GAP -- an exact null space (duplicated landmarks): lstsq's (gelsd's) cut-off is well defined there and is
+    //    reproduced: minimum-norm solution from a one-sided Jacobi SVD, singular values <= eps * sigma_max dropped
+    //    (nk_pinv.hip).
+    //  * NOISE -- the spectrum decays through the rounding level without a gap (the gamma = 1e-7 candidates of the
+    //    cloth grid): gelsd's rank decision is taken inside its own rounding noise, and no solver -- LAPACK's own
+    //    gelsy, Cholesky / LU or a truncated eigen-solve included -- is closer to it than a few 1e-3 on the held-out
+    //    score (tests/golden/make_golden_envelope.py, profiles/r03_cloth_units.txt).  The SVD (20-35 Jacobi sweeps)
+    //    buys nothing there: the system is factorised again with the smallest diagonal shift that makes it
+    //    numerically positive definite (NYSKOOP_SHIFT_FACTOR x m x eps x ||P||_inf, default 4), i.e. solved at full
+    //    rank like LAPACK's LU does when its Cholesky fails.  If that fails too, the SVD takes over.
+    //    NYSKOOP_NOISE_SVD=1 sends this class to the SVD as well (round-2 behaviour).
+    static const bool noise_svd = getenv("NYSKOOP_NOISE_SVD") && getenv("NYSKOOP_NOISE_SVD")[0] == '1';
+    static const double shift_factor = getenv("NYSKOOP_SHIFT_FACTOR") ? atof(getenv("NYSKOOP_SHIFT_FACTOR")) : 4.0;
     const double rcond = 2.220446049250313e-16;
     for (int q = 0; q < 2; ++q) {
       if (!chol_failed[q]) continue;
+      const size_t off = q == 0 ? 0 : gram_block1(m, p);                    // [matrix ; right-hand-side rows] of system q
+      const size_t cnt = q == 0 ? (size_t)(2 * m + p) * mp : (size_t)(m + d) * m;
+      const int mq = sys[q].m;
+      bool solved = false;
+      if (chol_kind[q] == CHOL_FAIL_NOISE && !noise_svd) {
+        NK_HIP(hipMemcpyAsync(G1 + off, Gsave + off, cnt * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+        NK_TRY(launch_max_abs_rowsum(ctx, Gsave + off, mq, mq, ctx->d_scalars + 20));
+        NK_HIP(hipMemcpyAsync(ctx->h_scalars + 20, ctx->d_scalars + 20, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        NK_HIP(hipStreamSynchronize(ctx->stream));
+        const double shift = shift_factor * (double)mq * rcond * ctx->h_scalars[20];
+        NK_TRY(launch_add_diag(ctx, G1 + off, mq, mq, shift));
+        NK_TRY(cholesky_aug_pair_async(ctx, &sys[q], 1));
+        int f1[1] = {0};
+        NK_TRY(cholesky_fail_flags(ctx, &sys[q], 1, f1));
+        solved = f1[0] >= 0 && f1[0] == 0;
+        if (f1[0] == -1) solved = true;  // rounding-level pivots after the shift: still a complete factorisation
+        if (solved) count_event(CNT_SHIFTED_SOLVE);
+      }
+      if (solved) continue;
       PinvInfo pi;
       if (q == 0)  // cross inner^+  ->  G2
         NK_TRY(pinv_right_divide(ctx, Gsave, mp, mp, Gsave + (size_t)mp * mp, mp, m, G2, mp, rcond, &pi));
@@ -1327,8 +1363,8 @@ static int fit_impl(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int6
         return NK_ERR_NO_CONVERGENCE;
       }
       rank_sys[q] = pi.rank;
+      count_event(CNT_RANK_TRUNCATED);
     }
-    count_event(CNT_RANK_TRUNCATED);
     redo_products = true;
   }
   {

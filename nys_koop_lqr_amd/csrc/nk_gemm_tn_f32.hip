@@ -3,7 +3,7 @@
 // 151,153,162,164) on v_mfma_f32_32x32x2_f32 -- twice the rate of the fp64 matrix pipe, half the bytes of every operand.
 // Everything m x m (the regularised systems, the square root, the operators) stays fp64: the Gram accumulators leave this
 // engine as fp64 (each workgroup moves its fp32 accumulators into fp64 shadow registers every `flush_steps` k-steps, so
-// no fp32 sum runs over more than a few thousand rows; partial tiles and their reduction are fp64, shared with the fp64
+// no fp32 sum runs over more than 32 rows by default; partial tiles and their reduction are fp64, shared with the fp64
 // engine).  Opt-in only (nk_set_compute_dtype): fp32 cannot reach the 1e-6 operator bar of the fp64 path.
 //
 // Same structure as nk_gemm_tn.hip: C = A^T B with both operands contraction-major (rows = k), 128 x 128 tile, 256 threads
@@ -320,7 +320,10 @@ int launch_gemm_tn_f32_multi(nk_ctx* ctx, const TnProblemF* probs, int nprob, in
   P.nprob = nprob; P.ntiles = ntiles; P.K = (int)K; P.splitk = splitk;
   P.klen = ((ktiles_total + splitk - 1) / splitk) * FBK;
   if (P.klen == 0) P.klen = FBK;
-  P.flush_steps = getenv("NYSKOOP_F32_FLUSH") ? atoi(getenv("NYSKOOP_F32_FLUSH")) : 32;  // 1024 rows per fp32 partial sum
+  // fp32 partial sums run over ONE k-step (32 rows) before they are added to the fp64 shadow: the conversions hide in the
+  // shadow of the MFMAs (3.72 against 3.58 ms per launch with 32 steps on the C5 twin) and the operators of an
+  // ill-conditioned fit feel every lost bit (tools/f32_diag.py)
+  P.flush_steps = getenv("NYSKOOP_F32_FLUSH") ? atoi(getenv("NYSKOOP_F32_FLUSH")) : 1;
   if (P.flush_steps < 1) P.flush_steps = 1;
   P.zeros = reinterpret_cast<const float*>(ctx->d_zeros);
   const ArenaMark mark = arena_mark(ctx);

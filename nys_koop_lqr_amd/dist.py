@@ -133,7 +133,9 @@ def sample_sharded_fit(reg, X_local, Y_local, landmark_rows=None):
         rank, world = 0, 1
     else:
         rank, world = dist.get_rank(), dist.get_world_size()
-    use_cuda = world > 1 and dist.get_backend() == "nccl"
+    # (a one-rank nccl group takes the device path too: RCCL initialises and reduces over one rank, so the branch the
+    # multi-GPU runs use is exercised on a single-GPU box -- tests/test_gpu_round3.py)
+    use_cuda = dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl"
     dev = torch.device("cuda", torch.cuda.current_device()) if use_cuda else torch.device("cpu")
     counts = torch.zeros(world, dtype=torch.int64, device=dev)
     counts[rank] = n_local
@@ -176,7 +178,7 @@ def sample_sharded_fit(reg, X_local, Y_local, landmark_rows=None):
     # `fit_from_gram` orders the library's (non-blocking) streams after torch's current stream (nk_wait_stream through
     # Context.wait_for) -- and torch's current stream after the collective through work.wait() -- before it reads the sum.
     reg.gram_partial(X_local, Y_local, out=gram if use_cuda else gram.numpy())
-    if world > 1:
+    if world > 1 or use_cuda:
         work = dist.all_reduce(gram, async_op=True)
         work.wait()  # nccl: torch's current stream now waits for the collective; gloo: blocks until done
     reg.fit_from_gram(gram if use_cuda else gram.numpy(), n_total, d)

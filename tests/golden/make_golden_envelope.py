@@ -8,6 +8,9 @@ be closer to the reference than LAPACK's other drivers are, so the bar of a unit
 
   spread_u    how far the reference's own score moves when its inputs are perturbed by one part in 1e15
               (its reproducibility), and
+  roworder_u  how far it moves when the SAME reference code sees the SAME samples in another row order (the fit is a sum
+              over samples: mathematically the same fit, numerically another summation order -- the GPU's Gram
+              contraction necessarily sums in its own order), and
   envelope_u  how far the score moves when the SAME reference code calls another LAPACK driver for the two solves
               (scipy.linalg.lstsq(..., lapack_driver='gelsy'), a Cholesky solve, a symmetric eigen-solve with gelsd's
               eps * sigma_max cut-off): the largest of the three deviations from the gelsd score.
@@ -142,10 +145,35 @@ def duffing():
                                relf(K, g[f"lqr_K_{seed}"]), relf(us, g[f"lqr_us_{seed}"]), relf(st, g[f"lqr_states_{seed}"])])
                 lqr_env[int(seed)] = np.maximum(lqr_env[int(seed)], d4)
     print("duffing LQR envelope (operators, K, controls, states) by seed:", lqr_env, flush=True)
+    # the reference itself (gelsd) on the same samples in another row order: sweep, operators of (seed 0; 10, 48, 200), LQR chain
+    perm = np.random.default_rng(5).permutation(X.shape[0])
+    Xr, Yr = np.ascontiguousarray(X[perm]), np.ascontiguousarray(Y[perm])
+    rm_r = np.zeros_like(ref)
+    op_r = {10: 0.0, 48: 0.0, 200: 0.0}
+    for si, seed in enumerate(g["seeds"]):
+        for k, m in enumerate(ms):
+            reg = R.KoopmanNystromRegressor(1, kernel=R.KernelWrapper([1, 1]), gamma=float(g["gamma"]), m=int(m))
+            reg.nystrom_centers_output = Y.T[:, g[f"idx_{seed}_{k}"]]
+            reg.fit(Xr, Yr)
+            rm_r[si, k] = MD.validate_dyn_sys(reg, g[f"traj_{seed}"], g[f"ctrl_{seed}"])[0]
+            if seed == 0 and int(m) in op_r:
+                op_r[int(m)] = max(relf(reg.A, g[f"A_m{m}"]), relf(reg.B, g[f"B_m{m}"]), relf(reg.C, g[f"C_m{m}"]))
+    roworder = np.abs(rm_r - ref) / ref
+    lqr_row = {}
+    for seed in g["seeds"]:
+        reg = R.KoopmanNystromRegressor(1, kernel=R.KernelWrapper([1, 1]), gamma=float(g["gamma"]), m=20)
+        reg.nystrom_centers_output = Y.T[:, g[f"lqr_idx_{seed}"]]
+        reg.fit(Xr, Yr)
+        K, _, us, st = MD.closed_loop(ds, reg, x0, reference, steps)
+        lqr_row[int(seed)] = np.array([max(relf(reg.A, g[f"lqr_A_{seed}"]), relf(reg.B, g[f"lqr_B_{seed}"]), relf(reg.C, g[f"lqr_C_{seed}"])),
+                                       relf(K, g[f"lqr_K_{seed}"]), relf(us, g[f"lqr_us_{seed}"]), relf(st, g[f"lqr_states_{seed}"])])
+    print("duffing: reference in another row order: rmse max rel %.2e; operators %s; LQR %s" % (roworder.max(), op_r, lqr_row), flush=True)
     env = np.max(np.stack(list(dev.values())), axis=0)
     print("duffing operator envelope (seed 0):", op_dev)
     np.savez_compressed(f"{OUT}/f12b_duffing_envelope.npz", envelope=env, op_envelope_m=np.array(sorted(op_dev)),
-                        op_envelope=np.array([op_dev[k] for k in sorted(op_dev)]),
+                        op_envelope=np.array([op_dev[k] for k in sorted(op_dev)]), roworder=roworder,
+                        op_roworder=np.array([op_r[k] for k in sorted(op_r)]),
+                        **{f"lqr_roworder_{k}": v for k, v in lqr_row.items()},
                         **{f"lqr_envelope_{k}": v for k, v in lqr_env.items()}, **{f"dev_{k}": v for k, v in dev.items()})
     print("duffing envelope by m (max over seeds):", dict(zip(ms.tolist(), np.round(env.max(axis=0), 6).tolist())))
 

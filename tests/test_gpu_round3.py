@@ -72,7 +72,7 @@ def test_runtime_counters_count_the_rank_truncating_branch(nk):
     reg.fit(X, Y)
     after = _lib.runtime_counters()
     assert after["rank_truncated_fits"] == before["rank_truncated_fits"] + 1
-    assert set(after) == {"chain_giveups", "jacobi_giveups", "rank_truncated_fits", "sqrt_retries"}
+    assert set(after) == {"chain_giveups", "jacobi_giveups", "rank_truncated_fits", "sqrt_retries", "shifted_solves"}
 
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (2006, 2000, 1000), (384, 2000, 777), (130, 258, 17), (2, 2, 3),
@@ -136,3 +136,36 @@ print("HASH", h)
         assert out.returncode == 0, (out.stdout[-300:], out.stderr[-1500:])
         hashes.append([l for l in out.stdout.splitlines() if l.startswith("HASH")][0])
     assert hashes[0] == hashes[1]
+
+
+def test_sample_sharded_fit_through_rccl_with_one_rank():
+    """The device branch of dist.sample_sharded_fit (packed Gram accumulator in HBM -> RCCL all-reduce on torch's stream
+    -> nk_wait_stream -> nk_nystrom_solve) with backend 'nccl' and ONE rank: RCCL initialises, the collective runs on
+    the device buffer, and the operators equal those of the plain fit bit for bit (one shard: same summation order).
+    The multi-rank runs are the driver's; this keeps the branch they take executed on the one-GPU box."""
+    code = r'''
+import os, sys, numpy as np
+sys.path.insert(0, %r)
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+os.environ["RANK"] = "0"; os.environ["WORLD_SIZE"] = "1"; os.environ["LOCAL_RANK"] = "0"
+import torch, torch.distributed as dist
+import nys_koop_lqr_amd as nk
+from nys_koop_lqr_amd import dist as nkd
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1)
+rng = np.random.default_rng(2)
+n, d, p, m = 4000, 48, 3, 256
+S = rng.standard_normal((n, d)); U = rng.standard_normal((n, p))
+Y = np.tanh(S @ (rng.standard_normal((d, d)) * 0.9 / np.sqrt(d))) + U @ (rng.standard_normal((p, d)) * 0.1)
+X = np.hstack([S, U])
+mk = lambda: nk.KoopmanNystromRegressor(p, kernel=nk.ThreeDimensionalKernel(6., 6., 6., d), gamma=1e-5, m=m)
+a = mk(); a.nystrom_centers_output = np.ascontiguousarray(Y[:m].T); a.fit(X, Y)
+b = mk(); b.nystrom_centers_output = np.ascontiguousarray(Y[:m].T)
+Xd, Yd = torch.as_tensor(X).cuda(), torch.as_tensor(Y).cuda()
+nkd.sample_sharded_fit(b, Xd, Yd)
+print("EQUAL", bool(np.array_equal(a.A, b.A) and np.array_equal(a.B, b.B) and np.array_equal(a.C, b.C)), dist.get_backend())
+dist.destroy_process_group()
+''' % ROOT
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, (out.stdout[-300:], out.stderr[-2000:])
+    assert "EQUAL True nccl" in out.stdout, out.stdout[-300:]

@@ -8,10 +8,9 @@ import json,sys
 j=json.loads(sys.stdin.read().strip().splitlines()[-1]); s=j['stages_ms']
 print('ms/fit %.2f | total %.2f kmat %.2f gram %.2f sqrt %.2f solve %.2f' % (j['ms_per_step'], s['ms_total'], s['ms_kmat'], s['ms_gram'], s['ms_sqrt'], s['ms_solve']))" >> $L 2>&1; }
 run A=base
-run NYSKOOP_SIDE_RESERVE_CUS=2
-run NYSKOOP_SIDE_RESERVE_CUS=4
-run NYSKOOP_SIDE_RESERVE_CUS=8
-run NYSKOOP_SIDE_RESERVE_CUS=4 NYSKOOP_CHOL_LOOKAHEAD=1
-run NYSKOOP_SIDE_RESERVE_CUS=8 NYSKOOP_CHOL_LOOKAHEAD=1
+run NYSKOOP_SQRT_AFTER_CHAIN=1
+run NYSKOOP_SQRT_AFTER_CHAIN=1 NYSKOOP_CHOL_LOOKAHEAD=1
+run NYSKOOP_SQRT_AFTER_CHAIN=1 NYSKOOP_CHOL_LOOKAHEAD=1 NYSKOOP_CHOL_LOOKAHEAD_PREP=1
+run NYSKOOP_CHOL_LOOKAHEAD=1
 run A=base
 cat $L
