@@ -159,10 +159,8 @@ int nk_group_stats(nk_ctx* member, uint64_t* out4);
  *   out[1] single-launch Jacobi sweeps (rank-truncating branch of the fit inside a lock-step group) that gave up the
  *          same way and finished with one launch per round;
  *   out[2] fits whose regularised system(s) took the rank-truncating branch (regressors.py:155,165: lstsq / gelsd);
- *   out[3] fits that repeated the matrix square root with the factorisation-free iteration;
- *   out[4] regularised systems without a spectral gap (pivots decaying through the rounding level) that were solved at
- *          full rank after a minimal diagonal shift instead of going through the SVD.
- * n = number of entries the caller provides (<= 5 are written). */
+ *   out[3] fits that repeated the matrix square root with the factorisation-free iteration.
+ * n = number of entries the caller provides (<= 4 are written). */
 int nk_runtime_counters(uint64_t* out, int32_t n);
 /* Releases everything the library still holds on every device -- live contexts (their streams, events and workspaces),
  * live models, the model-buffer pool and page-locked host blocks -- after waiting for pending work.  Handles that were

@@ -171,10 +171,9 @@ def runtime_counters():
     """Process-wide counts of the library's silent slow paths (nk_runtime_counters): single-launch recursions and Jacobi
     sweeps that gave up waiting for non-resident workgroups, fits that took the rank-truncating branch of the
     reference's lstsq (regressors.py:155,165), fits that repeated the matrix square root."""
-    v = (C.c_uint64 * 5)()
-    check(load_library().nk_runtime_counters(v, 5))
-    return dict(chain_giveups=int(v[0]), jacobi_giveups=int(v[1]), rank_truncated_fits=int(v[2]), sqrt_retries=int(v[3]),
-                shifted_solves=int(v[4]))
+    v = (C.c_uint64 * 4)()
+    check(load_library().nk_runtime_counters(v, 4))
+    return dict(chain_giveups=int(v[0]), jacobi_giveups=int(v[1]), rank_truncated_fits=int(v[2]), sqrt_retries=int(v[3]))
 
 
 def torch_if_cuda():

@@ -137,7 +137,7 @@ int group_enter(nk_ctx* c);
 int group_leave(nk_ctx* c);
 void group_stats(nk_ctx* c, uint64_t out[4]);
 // slow-path counters (nk_runtime_counters)
-enum { CNT_CHAIN_GIVEUP = 0, CNT_JACOBI_GIVEUP = 1, CNT_RANK_TRUNCATED = 2, CNT_SQRT_RETRY = 3, CNT_SHIFTED_SOLVE = 4, CNT_N = 5 };
+enum { CNT_CHAIN_GIVEUP = 0, CNT_JACOBI_GIVEUP = 1, CNT_RANK_TRUNCATED = 2, CNT_SQRT_RETRY = 3, CNT_N = 4 };
 void count_event(int which);
 uint64_t read_counter(int which);
 hipError_t real_stream_sync(hipStream_t s);
@@ -281,11 +281,7 @@ struct PinvInfo {
 int pinv_right_divide(nk_ctx* ctx, const double* P, int64_t ldp, int m, const double* E, int64_t lde, int rows,
                       double* E_out, int64_t ldeo, double rcond, PinvInfo* info);
 // which systems of the last (paired) factorisation on the current stream met a non-positive pivot (synchronises)
-// kind (optional, nsys entries): why a system was flagged -- CHOL_FAIL_GAP: the pivots show an exact null space (a cluster
-// of rounding-level or non-positive pivots isolated from healthy ones: duplicated landmarks), where lstsq's rank cut-off
-// is well defined; CHOL_FAIL_NOISE: the pivots decay gradually down to the rounding level (no gap), where it is not.
-enum { CHOL_FAIL_NONE = 0, CHOL_FAIL_GAP = 1, CHOL_FAIL_NOISE = 2 };
-int cholesky_fail_flags(nk_ctx* ctx, const CholSys* sys, int nsys, int* failed /* nsys entries */, int* kind = nullptr);
+int cholesky_fail_flags(nk_ctx* ctx, const CholSys* sys, int nsys, int* failed /* nsys entries */);
 
 // matrix-vector step of the lifted recursion for up to 8 trajectories (nk_rollout.hip)
 int launch_lifted_step(nk_ctx* ctx, const double* G, int64_t ldg, int m, int mz, int pu, const double* z, int64_t zstride,

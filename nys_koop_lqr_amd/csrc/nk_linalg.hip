@@ -516,7 +516,7 @@ int cholesky_check_pair(nk_ctx* ctx, const CholSys* sys, int nsys) {
 // a hyper-parameter grid: genuine pivots of 1e-13 d_max across the whole gamma = 1e-7 row of the cloth grid -- has no such
 // gap and is solved at full rank: there the reference's own rank decision is rounding noise and the
 // SVD path would cost 100 x more for an answer no closer to it.  Synchronises the current stream.
-int cholesky_fail_flags(nk_ctx* ctx, const CholSys* sys, int nsys, int* failed, int* kind) {
+int cholesky_fail_flags(nk_ctx* ctx, const CholSys* sys, int nsys, int* failed) {
   const int ib = info_base(ctx);
   std::vector<double> plog[2];
   NK_HIP(hipMemcpyAsync(ctx->h_info + ib, ctx->d_info + ib, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
@@ -531,44 +531,18 @@ int cholesky_fail_flags(nk_ctx* ctx, const CholSys* sys, int nsys, int* failed, 
   const double eps = 2.220446049250313e-16;
   for (int q = 0; q < nsys; ++q) {
     failed[q] = ctx->h_info[ib + q];
-    if (kind) kind[q] = CHOL_FAIL_NONE;
+    if (failed[q] != 0) continue;
     double dmin, dmax;
     memcpy(&dmin, &ctx->h_piv[2 * (ib + q)], 8);
     memcpy(&dmax, &ctx->h_piv[2 * (ib + q) + 1], 8);
-    if (failed[q] != 0) {
-      // a non-positive pivot at index failed[q] - 1.  Out of the blue (every pivot accepted before it 1000 x above the
-      // rounding window: an exact dependency, e.g. a duplicated landmark) or at the end of a gradual decay?
-      if (kind) {
-        kind[q] = CHOL_FAIL_GAP;
-        if (!plog[q].empty()) {
-          const int upto = std::min<int>(failed[q] - 1, (int)plog[q].size());
-          double pmax = 0.0, pmin = 1e308;
-          for (int i = 0; i < upto; ++i)
-            if (plog[q][i] > 0.0) { pmax = std::max(pmax, plog[q][i]); pmin = std::min(pmin, plog[q][i]); }
-          const double window = 8.0 * (double)sys[q].m * eps * pmax;
-          if (upto > 0 && pmin < 1000.0 * window) kind[q] = CHOL_FAIL_NOISE;
-        }
-      }
-      continue;
-    }
     if (!(dmax > 0.0)) continue;
-    bool gap = false;
-    if (!plog[q].empty()) {
-      std::sort(plog[q].begin(), plog[q].end());
-      const double window = 8.0 * (double)sys[q].m * eps * dmax;
-      size_t k = 0;
-      while (k < plog[q].size() && plog[q][k] <= window) ++k;
-      gap = k > 0 && k < plog[q].size() && plog[q][k] >= 1000.0 * plog[q][k - 1];
-    }
-    if (dmin <= eps * dmax) {
-      failed[q] = -1;
-      if (kind) kind[q] = gap ? CHOL_FAIL_GAP : CHOL_FAIL_NOISE;
-      continue;
-    }
-    if (gap) {
-      failed[q] = -1;
-      if (kind) kind[q] = CHOL_FAIL_GAP;
-    }
+    if (dmin <= eps * dmax) { failed[q] = -1; continue; }
+    if (plog[q].empty()) continue;
+    std::sort(plog[q].begin(), plog[q].end());
+    const double window = 8.0 * (double)sys[q].m * eps * dmax;
+    size_t k = 0;
+    while (k < plog[q].size() && plog[q][k] <= window) ++k;
+    if (k > 0 && k < plog[q].size() && plog[q][k] >= 1000.0 * plog[q][k - 1]) failed[q] = -1;
   }
   return NK_OK;
 }
