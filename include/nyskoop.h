@@ -98,7 +98,10 @@ int nk_set_kmat_mode(nk_ctx* ctx, int mode);
  * by a factor 1000: an exact null space), i.e. a matrix that is singular to working precision.  (A system whose Cholesky succeeds with healthy pivots is solved at full rank even if its singular values
  * reach below eps * sigma_max: there gelsd's rank decision is taken inside its own rounding noise and no two solvers
  * agree on it -- DESIGN.md section 3.)  strict = 1 turns the fallback into NK_ERR_NOT_SPD (also: environment variable
- * NYSKOOP_STRICT_SPD=1 before nk_create). */
+ * NYSKOOP_STRICT_SPD=1 before nk_create).  strict = 2 is the lstsq-shaped mode: BOTH regularised systems of every fit go
+ * through the SVD and are cut at eps * sigma_max exactly as gelsd cuts -- 10-50 x slower for small fits and, on the
+ * ill-conditioned candidates it was asked for, no closer to the reference than the default (profiles/r03_cloth_units.txt);
+ * kept for callers who want lstsq's rank rule whatever it costs. */
 int nk_set_strict_spd(nk_ctx* ctx, int strict);
 /* Arithmetic of the two O(n m d) kernel blocks and the O(n m^2) Gram contractions of nk_nystrom_fit / nk_nystrom_gram
  * (regressors.py:141-142,151,153,162,164).  NK_DTYPE_F64 (default): fp64 end to end, the only mode that meets the 1e-6

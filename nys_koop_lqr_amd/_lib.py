@@ -256,8 +256,9 @@ class Context:
 
     def set_strict_spd(self, strict):
         """True: a numerically rank-deficient regularised system raises LinAlgError (NK_ERR_NOT_SPD) instead of being
-        solved like scipy.linalg.lstsq does (minimum-norm solution, singular values <= eps * sigma_max dropped)."""
-        check(self.lib.nk_set_strict_spd(self.handle, 1 if strict else 0))
+        solved like scipy.linalg.lstsq does (minimum-norm solution, singular values <= eps * sigma_max dropped).
+        2 / "lstsq": every regularised system goes through the SVD with gelsd's cut-off, ill-conditioned or not."""
+        check(self.lib.nk_set_strict_spd(self.handle, 2 if strict in (2, "lstsq") else (1 if strict else 0)))
 
     def wait_for(self, *objs):
         """Order the context's streams after the work queued on torch's current stream whenever one of `objs` is a

@@ -519,8 +519,8 @@ int nk_set_compute_dtype(nk_ctx* ctx, int dtype) {
 }
 
 int nk_set_strict_spd(nk_ctx* ctx, int strict) {
-  NK_REQUIRE(ctx != nullptr, "nk_set_strict_spd: null context");
-  ctx->strict_spd = strict ? 1 : 0;
+  NK_REQUIRE(ctx != nullptr && strict >= 0 && strict <= 2, "nk_set_strict_spd: bad argument");
+  ctx->strict_spd = strict;
   return NK_OK;
 }
 
@@ -1310,8 +1310,9 @@ static int fit_impl(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int6
   tr.mark("final sync");
   int rank_sys[2] = {mp, m};
   bool redo_products = false;
+  if (ctx->strict_spd == 2) chol_failed[0] = chol_failed[1] = -1;  // lstsq-shaped: always the SVD with gelsd's cut-off
   if (chol_failed[0] || chol_failed[1]) {
-    if (ctx->strict_spd) {  // NK_ERR_NOT_SPD
+    if (ctx->strict_spd == 1) {  // NK_ERR_NOT_SPD
       set_error("Cholesky: system %d is numerically rank deficient (non-positive or rounding-level pivot; the reference's "
                 "lstsq truncates here) and strict mode is on", chol_failed[0] ? 0 : 1);
       return NK_ERR_NOT_SPD;
@@ -2114,7 +2115,7 @@ int nk_solve_spd(nk_ctx* ctx, const double* P, int64_t ldp, int32_t m, const dou
   csys.P = L; csys.ldp = m; csys.m = m; csys.Linv = Linv; csys.pivlog = pivlog;
   int rc_chol = cholesky_lower_pair(ctx, &csys, 1);
   if (getenv("NYSKOOP_FORCE_PINV")) rc_chol = NK_ERR_NOT_SPD;  // testing hook: always take the SVD path
-  if (rc_chol == NK_ERR_NOT_SPD && !ctx->strict_spd) {
+  if (rc_chol == NK_ERR_NOT_SPD && ctx->strict_spd != 1) {
     // numerically singular: X = P^+ R with gelsd's cut-off, i.e. X^T = R^T P^+ (P symmetric)
     double *Rt = nullptr, *Xt = nullptr;
     NK_TRY(arena_alloc_t(ctx, (size_t)nrhs * m, &Rt));

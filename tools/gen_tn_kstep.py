@@ -138,106 +138,6 @@ def main():
     emit("NK_TN_KSTEPS_ASM", whole, (64 * 5, 32 * 3 + 24 * 2, 8 * 3))
 
 
-if __name__ == "__main__" and len(sys.argv) == 1:
+if __name__ == "__main__":
     main()
 
-
-# ---------------------------------------------------------------------------------------------------------------------------
-# fp32 engine (nk_gemm_tn_f32.hip): the same schedule for v_mfma_f32_32x32x2_f32.  A k-step is 32 contraction rows = 16 k-pairs;
-# a wave's 64 x 64 sub-tile is 2 x 2 blocks of 32 x 32 (4 accumulators of 16 VGPRs); a k-pair needs 2 + 2 one-VGPR fragments
-# (lane (half, l32) holds row 2 kk + half, column l32 of the block), fetched with ds_read_b32 one k-pair ahead.
-#     python3 tools/gen_tn_kstep.py f32 > nys_koop_lqr_amd/csrc/nk_tnf_kstep.inc
-# ---------------------------------------------------------------------------------------------------------------------------
-F_ROW_B = 128 * 4            # bytes per LDS row (unpadded)
-F_PAIR_B = 2 * F_ROW_B       # bytes per k-pair
-F_PANEL_B = 32 * F_ROW_B     # B panel after the A panel
-
-
-def f32_main():
-    lines = []
-
-    def mf(i, j, s):
-        return f"v_mfma_f32_32x32x2_f32 %[c{i}{j}], %[a{s}{i}], %[b{s}{j}], %[c{i}{j}]"
-
-    def rd(kk, s, stage):
-        ra, rb = f"%[ard{stage}]", f"%[brd{stage}]"
-        return [f"ds_read_b32 %[a{s}0], {ra} offset:{kk * F_PAIR_B}", f"ds_read_b32 %[a{s}1], {ra} offset:{kk * F_PAIR_B + 128}",
-                f"ds_read_b32 %[b{s}0], {rb} offset:{kk * F_PAIR_B}", f"ds_read_b32 %[b{s}1], {rb} offset:{kk * F_PAIR_B + 128}"]
-
-    def dma(stage):
-        seq = [f"s_mov_b32 m0, %[dst{stage}]"]
-        for q in range(4):
-            seq += ["s_nop 0", "global_load_lds_dwordx4 %[voa], s[92:93]", f"s_add_u32 m0, m0, {F_PANEL_B}",
-                    "s_add_u32 s92, s92, %[stra]", "s_addc_u32 s93, s93, 0", "global_load_lds_dwordx4 %[vob], s[94:95]"]
-            if q < 3:
-                seq += [f"s_sub_u32 m0, m0, {F_PANEL_B - 4 * F_PAIR_B}"]
-            seq += ["s_add_u32 s94, s94, %[strb]", "s_addc_u32 s95, s95, 0"]
-        return seq
-
-    def step(st, last=False):
-        """Fragment sets kk & 3; the fragments of k-pair kk + 2 are fetched in the gaps of k-pair kk (two k-pairs = 8 MFMAs of
-        LDS latency cover), so the wait before a k-pair leaves the 4 youngest reads in flight.  On entry sets 0 and 1 hold
-        k-pairs 0 and 1 (set 1 possibly still in flight); on exit they hold those of the next stage."""
-        d = [] if last else dma(1 - st)
-        per = (len(d) + 31) // 32 if d else 0
-        di = 0
-        issued_prev = 4  # reads issued during the previous k-pair (k-pair 1's, by the previous step or the caller)
-        for kk in range(16):
-            s = kk & 3
-            if kk == 14 and not last:
-                # every read of this stage has been issued (k-pair 15's during k-pair 13): drain them, then the barrier
-                lines.extend(["s_waitcnt lgkmcnt(0)", "s_waitcnt vmcnt(0)", "s_barrier"])
-            else:
-                lines.append(f"s_waitcnt lgkmcnt({issued_prev})")
-            if kk + 2 <= 15:
-                nxt = rd(kk + 2, (kk + 2) & 3, st)
-            elif not last:
-                nxt = rd(kk - 14, kk - 14, 1 - st)   # k-pair 14 fetches the next stage's k-pair 0 (set 0), k-pair 15 its k-pair 1
-            else:
-                nxt = []
-            issued_prev = len(nxt)
-            for n, (i, j) in enumerate([(0, 0), (0, 1), (1, 0), (1, 1)]):
-                lines.append(mf(i, j, s))
-                if n < len(nxt):
-                    lines.append(nxt[n])
-                if d and 1 <= kk <= 8:
-                    lines.extend(d[di:di + per])
-                    di += per
-        assert di >= len(d)
-
-    def whole():
-        lines.extend(["s_mov_b64 s[92:93], %[rowa]", "s_mov_b64 s[94:95], %[rowb]",
-                      "s_cmp_eq_u32 %[cnt], 0", "s_cbranch_scc1 nk_tnf_after_%=", "nk_tnf_loop_%=:"])
-        step(0)
-        step(1)
-        lines.extend(["s_sub_u32 %[cnt], %[cnt], 1", "s_cmp_lg_u32 %[cnt], 0", "s_cbranch_scc1 nk_tnf_loop_%=",
-                      "nk_tnf_after_%=:", "s_bitcmp1_b32 %[flags], 0", "s_cbranch_scc0 nk_tnf_even_%="])
-        step(0)
-        lines.extend(["s_bitcmp1_b32 %[flags], 1", "s_cbranch_scc0 nk_tnf_end_%="])
-        step(1, last=True)
-        lines.extend(["s_branch nk_tnf_end_%=", "nk_tnf_even_%=:", "s_bitcmp1_b32 %[flags], 1", "s_cbranch_scc0 nk_tnf_end_%="])
-        step(0, last=True)
-        lines.append("nk_tnf_end_%=:")
-
-    whole()
-    print("// GENERATED by tools/gen_tn_kstep.py f32 -- do not edit by hand.")
-    print("// k-steps (32 contraction rows each) of the 128 x 128 fp32 tile (v_mfma_f32_32x32x2_f32), every non-matrix instruction in a")
-    print("// gap between two MFMAs.  Operands: c00 c01 c10 c11 (+v, 16 VGPRs each); a00 a01 b00 b01 / a10 a11 b10 b11 (+v: fragment sets")
-    print("// 0 and 1: k-pairs 0 and 1 of the current step on entry, of the next unprocessed step on exit); a2x b2x a3x b3x (=&v: scratch sets); ard0/brd0,")
-    print("// ard1/brd1 (v: LDS read addresses of the fragments in stage 0 / 1); voa/vob (v: per-lane byte offsets of the DMA, row")
-    print("// stride of the odd half included); rowa/rowb (s, 64 bit: this wave's first row pair of the step AFTER the current one);")
-    print("// stra/strb (s: 8 rows in bytes); dst0/dst1 (s: LDS byte address of this wave's first DMA row pair in stage 0 / 1).")
-    print("// NK_TNF_KSTEPS_ASM: cnt (+s) trips of TWO steady steps (stage 0, then 1); then, if bit 0 of flags (s) is set, ONE more steady")
-    print("// step (stage 0); then, if bit 1 is set, the final step of the K range (no DMA, no barrier).  Clobbers s[92:95], m0, scc.")
-    print("#define NK_TNF_KSTEPS_ASM \\")
-    for ln in lines:
-        print(f'  "{ln}\\n\\t" \\')
-    print('  ""')
-    nm = sum(1 for ln in lines if ln.startswith("v_mfma"))
-    nd = sum(1 for ln in lines if ln.startswith("global_load_lds"))
-    nr = sum(1 for ln in lines if ln.startswith("ds_read"))
-    assert (nm, nd, nr) == (64 * 5, 8 * 3, 64 * 3 + 56 * 2), (nm, nd, nr)
-
-
-if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "f32":
-    f32_main()
