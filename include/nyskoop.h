@@ -72,6 +72,16 @@ typedef struct nk_fit_stats {
    * scipy.linalg.lstsq (gelsd) reports as `rank` */
   int32_t rank_inner;
   int32_t rank_inner_rec;
+  /* smallest / largest Cholesky pivot of the two regularised systems (0 when the factorisation failed); below the
+   * threshold of nk_set_refine (off by default) the solve is refined with doubled-precision residuals while the corrections contract;
+   * `refined` = steps applied to inner + 16 x steps applied to inner_rec (0 = none); refine_ratio_* = |first correction| /
+   * |solution| (an estimate of cond x backward error of the factor; the first step is applied when it is <= 1/4) */
+  double pivot_ratio_inner;
+  double pivot_ratio_inner_rec;
+  int32_t refined;
+  int32_t reserved_;
+  double refine_ratio_inner;
+  double refine_ratio_inner_rec;
 } nk_fit_stats;
 
 typedef struct nk_ctx nk_ctx;
@@ -103,6 +113,13 @@ int nk_set_kmat_mode(nk_ctx* ctx, int mode);
  * ill-conditioned candidates it was asked for, no closer to the reference than the default (profiles/r03_cloth_units.txt);
  * kept for callers who want lstsq's rank rule whatever it costs. */
 int nk_set_strict_spd(nk_ctx* ctx, int strict);
+/* Optional refinement of the two regularised solves of a fit (regressors.py:155,165).  The blocked Cholesky solve is
+ * backward stable (every product with an inverted diagonal block takes a correction step from the data); a system whose
+ * smallest / largest pivot is below `pivot_ratio` can in addition be refined `steps` times with residuals accumulated in
+ * doubled precision, which returns the system's own solution to working precision whatever its condition (as long as
+ * cond x eps < 1/4: a step is applied only while the corrections contract).  pivot_ratio = 0 (default; also the
+ * environment variable NYSKOOP_REFINE_PIVOT before nk_create) = never.  nk_fit_stats.refined / refine_ratio_* report it. */
+int nk_set_refine(nk_ctx* ctx, double pivot_ratio, int32_t steps);
 /* Arithmetic of the two O(n m d) kernel blocks and the O(n m^2) Gram contractions of nk_nystrom_fit / nk_nystrom_gram
  * (regressors.py:141-142,151,153,162,164).  NK_DTYPE_F64 (default): fp64 end to end, the only mode that meets the 1e-6
  * operator bar.  NK_DTYPE_F32 (the stress configuration of BASELINE.json: n = 1e6, m = 8000, d = 1024, "fp32"): rows and
@@ -162,8 +179,9 @@ int nk_group_stats(nk_ctx* member, uint64_t* out4);
  *   out[1] single-launch Jacobi sweeps (rank-truncating branch of the fit inside a lock-step group) that gave up the
  *          same way and finished with one launch per round;
  *   out[2] fits whose regularised system(s) took the rank-truncating branch (regressors.py:155,165: lstsq / gelsd);
- *   out[3] fits that repeated the matrix square root with the factorisation-free iteration.
- * n = number of entries the caller provides (<= 4 are written). */
+ *   out[3] fits that repeated the matrix square root with the factorisation-free iteration;
+ *   out[4] fits whose regularised solves were refined with doubled-precision residuals (nk_set_refine).
+ * n = number of entries the caller provides (<= 5 are written). */
 int nk_runtime_counters(uint64_t* out, int32_t n);
 /* Releases everything the library still holds on every device -- live contexts (their streams, events and workspaces),
  * live models, the model-buffer pool and page-locked host blocks -- after waiting for pending work.  Handles that were

@@ -37,7 +37,9 @@ class FitStats(C.Structure):
                 ("ms_gram", C.c_double), ("ms_sqrt", C.c_double), ("ms_solve", C.c_double),
                 ("ms_gram_kernel_avg", C.c_double), ("gram_kernel_launches", C.c_int32),
                 ("sqrt_iters", C.c_int32), ("sqrt_residual", C.c_double), ("gram_flops", C.c_double),
-                ("kmat_pairs", C.c_double), ("rank_inner", C.c_int32), ("rank_inner_rec", C.c_int32)]
+                ("kmat_pairs", C.c_double), ("rank_inner", C.c_int32), ("rank_inner_rec", C.c_int32),
+                ("pivot_ratio_inner", C.c_double), ("pivot_ratio_inner_rec", C.c_double), ("refined", C.c_int32),
+                ("reserved_", C.c_int32), ("refine_ratio_inner", C.c_double), ("refine_ratio_inner_rec", C.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -59,6 +61,7 @@ SIGNATURES = {
     "nk_stream": (_P, [_P]),
     "nk_set_kmat_mode": (C.c_int, [_P, C.c_int]),
     "nk_set_strict_spd": (C.c_int, [_P, C.c_int]),
+    "nk_set_refine": (C.c_int, [_P, C.c_double, C.c_int32]),
     "nk_wait_stream": (C.c_int, [_P, _P]),
     "nk_shutdown": (C.c_int, []),
     "nk_group_create": (C.c_int, [C.c_int, C.c_int, C.POINTER(_P)]),
@@ -171,9 +174,10 @@ def runtime_counters():
     """Process-wide counts of the library's silent slow paths (nk_runtime_counters): single-launch recursions and Jacobi
     sweeps that gave up waiting for non-resident workgroups, fits that took the rank-truncating branch of the
     reference's lstsq (regressors.py:155,165), fits that repeated the matrix square root."""
-    v = (C.c_uint64 * 4)()
-    check(load_library().nk_runtime_counters(v, 4))
-    return dict(chain_giveups=int(v[0]), jacobi_giveups=int(v[1]), rank_truncated_fits=int(v[2]), sqrt_retries=int(v[3]))
+    v = (C.c_uint64 * 5)()
+    check(load_library().nk_runtime_counters(v, 5))
+    return dict(chain_giveups=int(v[0]), jacobi_giveups=int(v[1]), rank_truncated_fits=int(v[2]), sqrt_retries=int(v[3]),
+                refined_fits=int(v[4]))
 
 
 def torch_if_cuda():
@@ -259,6 +263,11 @@ class Context:
         solved like scipy.linalg.lstsq does (minimum-norm solution, singular values <= eps * sigma_max dropped).
         2 / "lstsq": every regularised system goes through the SVD with gelsd's cut-off, ill-conditioned or not."""
         check(self.lib.nk_set_strict_spd(self.handle, 2 if strict in (2, "lstsq") else (1 if strict else 0)))
+
+    def set_refine(self, pivot_ratio=1e-9, steps=2):
+        """Refine the regularised solves of fits whose smallest / largest Cholesky pivot is below `pivot_ratio` with
+        doubled-precision residuals (nk_set_refine); pivot_ratio = 0 switches it off (the default)."""
+        check(self.lib.nk_set_refine(self.handle, float(pivot_ratio), int(steps)))
 
     def wait_for(self, *objs):
         """Order the context's streams after the work queued on torch's current stream whenever one of `objs` is a

@@ -424,6 +424,8 @@ int nk_create(int device, nk_ctx** out) {
   ctx->kmat_mode = (km && strcmp(km, "direct") == 0) ? 1 : 0;
   const char* st = getenv("NYSKOOP_STRICT_SPD");
   ctx->strict_spd = (st && atoi(st) != 0) ? 1 : 0;
+  if (const char* rp = getenv("NYSKOOP_REFINE_PIVOT")) ctx->refine_pivot = atof(rp);
+  if (const char* rs = getenv("NYSKOOP_REFINE_STEPS")) ctx->refine_steps = std::max(0, atoi(rs));
   {
     std::lock_guard<std::mutex> lk(g_reg_mu);
     g_ctxs.insert(ctx);
@@ -521,6 +523,13 @@ int nk_set_compute_dtype(nk_ctx* ctx, int dtype) {
 int nk_set_strict_spd(nk_ctx* ctx, int strict) {
   NK_REQUIRE(ctx != nullptr && strict >= 0 && strict <= 2, "nk_set_strict_spd: bad argument");
   ctx->strict_spd = strict;
+  return NK_OK;
+}
+
+int nk_set_refine(nk_ctx* ctx, double pivot_ratio, int32_t steps) {
+  NK_REQUIRE(ctx != nullptr && pivot_ratio >= 0.0 && pivot_ratio <= 1.0 && steps >= 0 && steps <= 8, "nk_set_refine: bad argument");
+  ctx->refine_pivot = pivot_ratio;
+  ctx->refine_steps = steps;
   return NK_OK;
 }
 
@@ -930,6 +939,79 @@ static int fit_impl(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int6
   int gram_launches = 0;
   bool gram_deferred = false;
   const bool timed = stats != nullptr;
+  // ---- the matrix square root S = (K_mm + jitter I)^{1/2}, S^-1 (regressors.py:140,163) runs beside the main stream's work in
+  //      two parts, queued by the two lambdas below: the latency-bound preparation (preparation stream) and the GEMM-bound
+  //      iteration with the products that depend on S only (side stream), both behind the fused Gram launch and beside the
+  //      factorisation chain of the regularised systems.  (Round 3 also measured the whole square root queued BEFORE the Gram
+  //      launch, beside the kernel blocks, with the Gram launch waiting for it: 44.5 against 42.9 ms per fit -- the chain's
+  //      ~100 small kernels each wait for a workgroup slot of the long-running kernel blocks, the square root takes 13 ms
+  //      there instead of 9, and what the tail gains (the factorisation chain alone: 4.2 ms) the wait gives back.)
+  SqrtPlan splan;
+  int it = 0;
+  double resid = 0.0;
+  double *Sinvt = nullptr, *T1t = nullptr, *X1 = nullptr;
+  auto alloc_sqrt_bufs = [&]() -> int {
+    if (Sinvt == nullptr) NK_TRY(arena_alloc_t(ctx, (size_t)m * m, &Sinvt));
+    if (T1t == nullptr) NK_TRY(arena_alloc_t(ctx, (size_t)m * m, &T1t));
+    if (X1 == nullptr) NK_TRY(arena_alloc_t(ctx, (size_t)m * m, &X1));
+    return NK_OK;
+  };
+  // products that depend on the square root only (current stream)
+  auto sqrt_products = [&]() -> int {
+    NK_TRY(launch_transpose(ctx, mdl->Sinv, m, Sinvt, m, m, m));
+    if (same_centers) {
+      // K_xo = K_mm = S^2 - jitter I, hence K_xo S^-1 = S - jitter S^-1: no product (and a smaller rounding error than
+      // the product, whose terms are ||K|| ||S^-1|| large)
+      NK_TRY(launch_copy2d(ctx, mdl->S, m, T1t, m, m, m));
+      NK_TRY(launch_axpby2d(ctx, -jitter, mdl->Sinv, m, 1.0, T1t, m, m, m));
+    } else {
+      NK_TRY(launch_transpose(ctx, Kxo, m, X1, m, m, m));
+      NK_TRY(launch_gemm(ctx, true, false, m, m, m, 1.0, X1, m, mdl->Sinv, m, 0.0, T1t, m));
+    }
+    return NK_OK;
+  };
+  // Cholesky factor of K_mm + jitter and its inverse, the latency-bound half of the square root: small kernels on the
+  // preparation stream (queued behind the kernel-block / Gram launches so that the main stream is never kept waiting for
+  // the host)
+  auto queue_prep = [&]() -> int {
+    SideScope prep(ctx, ctx->stream_prep);
+    NK_HIP(hipStreamWaitEvent(ctx->stream, ev[8], 0));
+    // kernel matrices are positive semi-definite: the jitter bounds the smallest eigenvalue of K_mm + jitter I from
+    // below, which lets the iteration be queued before this factorisation has run (SqrtPlan::lambda_min_hint)
+    splan.lambda_min_hint = jitter > 0.0 ? jitter : 0.0;
+    // This chain of ~100 small high-priority kernels must not run beside the fused Gram launch: that launch fills the
+    // chip in exact rounds of 3-ms workgroups, and a Gram workgroup whose slot a chain kernel holds at a round boundary
+    // finds the next free slot a whole round later -- measured: the launch takes 26.5-27.0 ms inside the fit against 25.0
+    // alone.  So the chain waits for the Gram launch and runs after it -- ahead of the square-root iteration, which has
+    // that much slack against the factorisation chain of the regularised systems.  NYSKOOP_PREP_PAUSE = fraction of the
+    // block steps to run BEFORE the pause, beside the kernel blocks (1 = never pause).  Measured on one box, ms per fit:
+    // 1 -> 44.1, 0.75 -> 44.1, 0.5 -> 43.2, 0.25 -> 43.2, 0 (default) -> 42.9 (kernel blocks 6.9 -> 6.3, Gram 26.7 -> 25.5).
+    if (mode == FIT_FULL && n_eff >= 20000 && m >= 1024) {
+      static const double frac = getenv("NYSKOOP_PREP_PAUSE") ? atof(getenv("NYSKOOP_PREP_PAUSE")) : 0.0;
+      const int nb = (m + CHOL_NB - 1) / CHOL_NB;
+      if (frac < 1.0) {
+        splan.pause_event = ctx->ev_fork;  // recorded behind the last Gram launch
+        splan.pause_step = std::max(0, std::min(nb - 1, (int)(frac * nb)));
+      }
+    }
+    NK_TRY(sqrtm_prepare(ctx, Kj, m, m, &splan));
+    NK_HIP(hipEventRecord(ev[9], ctx->stream));
+    return NK_OK;
+  };
+  // the GEMM-bound iteration, then S^-T and K_xo S^-1, on the side stream
+  auto queue_side = [&]() -> int {
+    NK_TRY(alloc_sqrt_bufs());
+    SideScope side(ctx);
+    NK_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_fork, 0));  // starts when the Gram launch is done
+    NK_HIP(hipStreamWaitEvent(ctx->stream, ev[9], 0));
+    NK_HIP(hipEventRecord(ev[6], ctx->stream));
+    NK_TRY(sqrtm_finish(ctx, &splan, mdl->S, mdl->Sinv));
+    NK_HIP(hipEventRecord(ev[7], ctx->stream));
+    // still on the side stream (the factorisation chain is usually not finished yet): S^-T and K_xo S^-1
+    NK_TRY(sqrt_products());
+    NK_HIP(hipEventRecord(ctx->ev_join, ctx->stream));
+    return NK_OK;
+  };
   if (mode == FIT_SOLVE) {
     // the accumulated Gram blocks come from the caller (host or device memory)
     NK_HIP(hipMemcpyAsync(G1, gram_io, gram_doubles(m, d, p) * sizeof(double),
@@ -1186,34 +1268,7 @@ static int fit_impl(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int6
   NK_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));  // the square-root iteration starts when the Gram launch is done
   tr.mark("gram issued");
 
-  // ---- preparation stream (queued behind the kernel-block / Gram launches so that the main stream is never kept
-  //      waiting for the host): Cholesky factor of K_mm + jitter and its inverse, the latency-bound half of the matrix
-  //      square root.  Small kernels that slip into the gaps of the big launches.
-  SqrtPlan splan;
-  {
-    SideScope prep(ctx, ctx->stream_prep);
-    NK_HIP(hipStreamWaitEvent(ctx->stream, ev[8], 0));
-    // kernel matrices are positive semi-definite: the jitter bounds the smallest eigenvalue of K_mm + jitter I from
-    // below, which lets the iteration be queued before this factorisation has run (SqrtPlan::lambda_min_hint)
-    splan.lambda_min_hint = jitter > 0.0 ? jitter : 0.0;
-    // This chain of ~100 small high-priority kernels must not run beside the fused Gram launch: that launch fills the
-    // chip in exact rounds of 3-ms workgroups, and a Gram workgroup whose slot a chain kernel holds at a round boundary
-    // finds the next free slot a whole round later -- measured: the launch takes 26.5-27.0 ms inside the fit against 25.0
-    // alone.  So the chain waits for the Gram launch and runs after it -- ahead of the square-root iteration, which has
-    // that much slack against the factorisation chain of the regularised systems.  NYSKOOP_PREP_PAUSE = fraction of the
-    // block steps to run BEFORE the pause, beside the kernel blocks (1 = never pause).  Measured on one box, ms per fit:
-    // 1 -> 44.1, 0.75 -> 44.1, 0.5 -> 43.2, 0.25 -> 43.2, 0 (default) -> 42.9 (kernel blocks 6.9 -> 6.3, Gram 26.7 -> 25.5).
-    if (mode == FIT_FULL && n_eff >= 20000 && m >= 1024) {
-      static const double frac = getenv("NYSKOOP_PREP_PAUSE") ? atof(getenv("NYSKOOP_PREP_PAUSE")) : 0.0;
-      const int nb = (m + CHOL_NB - 1) / CHOL_NB;
-      if (frac < 1.0) {
-        splan.pause_event = ctx->ev_fork;  // recorded above, behind the last Gram launch
-        splan.pause_step = std::max(0, std::min(nb - 1, (int)(frac * nb)));
-      }
-    }
-    NK_TRY(sqrtm_prepare(ctx, Kj, m, m, &splan));
-    NK_HIP(hipEventRecord(ev[9], ctx->stream));
-  }
+  NK_TRY(queue_prep());
 
   // ---- the two regularised systems (regressors.py:151,162) are assembled, factorised AND solved on the main stream
   //      without waiting for the square root: with inner and inner_rec symmetric,
@@ -1229,15 +1284,12 @@ static int fit_impl(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int6
   double* Gsave = nullptr;
   NK_TRY(arena_alloc_t(ctx, gram_doubles(m, d, p), &Gsave));
   NK_HIP(hipMemcpyAsync(Gsave, G1, gram_doubles(m, d, p) * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
-  double *Linv = nullptr, *Linv2 = nullptr, *Sinvt = nullptr, *V1 = nullptr, *T1t = nullptr, *X1 = nullptr, *Wc = nullptr,
-         *Ct = nullptr;
+  double *Linv = nullptr, *Linv2 = nullptr, *V1 = nullptr, *Wc = nullptr, *Ct = nullptr;
   const int nblk = (mp + CHOL_NB - 1) / CHOL_NB;
-  NK_TRY(arena_alloc_t(ctx, (size_t)nblk * CHOL_NB * CHOL_NB, &Linv));
-  NK_TRY(arena_alloc_t(ctx, (size_t)nblk * CHOL_NB * CHOL_NB, &Linv2));
-  NK_TRY(arena_alloc_t(ctx, (size_t)m * m, &Sinvt));
+  NK_TRY(arena_alloc_t(ctx, (size_t)nblk * CHOL_WS, &Linv));
+  NK_TRY(arena_alloc_t(ctx, (size_t)nblk * CHOL_WS, &Linv2));
   NK_TRY(arena_alloc_t(ctx, (size_t)m * m, &V1));
-  NK_TRY(arena_alloc_t(ctx, (size_t)m * m, &T1t));
-  NK_TRY(arena_alloc_t(ctx, (size_t)m * m, &X1));
+  NK_TRY(alloc_sqrt_bufs());
   NK_TRY(arena_alloc_t(ctx, (size_t)m * ldd, &Wc));
   NK_TRY(arena_alloc_t(ctx, (size_t)m * ldd, &Ct));
   CholSys sys[2];
@@ -1253,34 +1305,7 @@ static int fit_impl(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int6
   // with look-ahead in both chains 43.7 / 47.5: the overlap of the two, slow as each becomes, is still the best schedule)
   tr.mark("cholesky + solves issued");
 
-  // ---- ... while S = K_mm^{1/2}, S^{-1} (regressors.py:140,163) runs on the side stream (GEMM bound) --------------------
-  int it = 0;
-  double resid = 0.0;
-  // products that depend on the square root only (current stream)
-  auto sqrt_products = [&]() -> int {
-    NK_TRY(launch_transpose(ctx, mdl->Sinv, m, Sinvt, m, m, m));
-    if (same_centers) {
-      // K_xo = K_mm = S^2 - jitter I, hence K_xo S^-1 = S - jitter S^-1: no product (and a smaller rounding error than
-      // the product, whose terms are ||K|| ||S^-1|| large)
-      NK_TRY(launch_copy2d(ctx, mdl->S, m, T1t, m, m, m));
-      NK_TRY(launch_axpby2d(ctx, -jitter, mdl->Sinv, m, 1.0, T1t, m, m, m));
-    } else {
-      NK_TRY(launch_transpose(ctx, Kxo, m, X1, m, m, m));
-      NK_TRY(launch_gemm(ctx, true, false, m, m, m, 1.0, X1, m, mdl->Sinv, m, 0.0, T1t, m));
-    }
-    return NK_OK;
-  };
-  {
-    SideScope side(ctx);
-    NK_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_fork, 0));
-    NK_HIP(hipStreamWaitEvent(ctx->stream, ev[9], 0));
-    NK_HIP(hipEventRecord(ev[6], ctx->stream));
-    NK_TRY(sqrtm_finish(ctx, &splan, mdl->S, mdl->Sinv));
-    NK_HIP(hipEventRecord(ev[7], ctx->stream));
-    // still on the side stream (the factorisation chain is usually not finished yet): S^-T and K_xo S^-1
-    NK_TRY(sqrt_products());
-    NK_HIP(hipEventRecord(ctx->ev_join, ctx->stream));
-  }
+  NK_TRY(queue_side());
   NK_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
   NK_HIP(hipEventRecord(ev[4], ctx->stream));
   tr.mark("side stream joined (queued)");
@@ -1306,7 +1331,8 @@ static int fit_impl(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int6
   NK_HIP(hipEventRecord(ev[5], ctx->stream));
   tr.mark("solve issued");
   int chol_failed[2] = {0, 0};
-  NK_TRY(cholesky_fail_flags(ctx, sys, 2, chol_failed));  // synchronises the main stream (which has joined the side stream)
+  double piv_ratio[2] = {1.0, 1.0};
+  NK_TRY(cholesky_fail_flags(ctx, sys, 2, chol_failed, piv_ratio));  // synchronises the main stream (which has joined the side stream)
   tr.mark("final sync");
   int rank_sys[2] = {mp, m};
   bool redo_products = false;
@@ -1341,6 +1367,50 @@ static int fit_impl(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int6
     count_event(CNT_RANK_TRUNCATED);
     redo_products = true;
   }
+  // ---- optional refinement of ill-conditioned systems (nk_set_refine / NYSKOOP_REFINE_PIVOT; off by default).  Each step
+  //      forms the residual R - X inner from the SAVED system in doubled precision (launch_resid_dd: a plain fp64 residual
+  //      is all rounding error and makes things worse) and solves for the correction with the same factor; a step is
+  //      applied only while the corrections contract (decided on the device).  The solution then is the system's own to
+  //      working precision -- what is left against the reference is the reference's rounding (gelsd) and the Gram
+  //      products' summation order.  With the backward-stable blocked solve (chol_panel_kernel) this buys little: config 2
+  //      A 1.5e-4 -> 1.15e-4 from the reference whose own row-order spread is 1.0e-4; it costs 10 flop per term on the
+  //      vector ALU (0.15 s on the 405-unit cloth grid), hence opt-in.
+  int refined[2] = {0, 0};
+  {
+    const double refine_below = ctx->refine_pivot;
+    const int refine_steps = ctx->refine_steps;
+    double* refine_state = nullptr;
+    NK_TRY(arena_alloc_t(ctx, (size_t)8, &refine_state));
+    for (int q = 0; q < 2 && refine_steps > 0; ++q) {
+      if (chol_failed[q] || !(piv_ratio[q] > 0.0) || piv_ratio[q] >= refine_below) continue;
+      const int mq = sys[q].m, nr = sys[q].extra;                       // system size, number of right-hand sides (rows)
+      const size_t off = q == 0 ? 0 : gram_block1(m, p);
+      const double* Pq = Gsave + off;                                   // saved system (symmetric)
+      const double* Rq = Gsave + off + (size_t)mq * mq;                 // saved right-hand-side rows (nr x mq)
+      double* Xq = G1 + off + (size_t)mq * mq;                          // solution rows (nr x mq) = R P^-1
+      const ArenaMark mk = arena_mark(ctx);
+      double *Res = nullptr, *ResT = nullptr, *partial = nullptr;
+      const int64_t ldt_ = nr + (nr & 1);
+      NK_TRY(arena_alloc_t(ctx, (size_t)nr * mq, &Res));
+      NK_TRY(arena_alloc_t(ctx, (size_t)mq * ldt_, &ResT));
+      NK_TRY(arena_alloc_t(ctx, (size_t)2 * refine_partial_blocks(), &partial));
+      CholSys y = sys[q];
+      y.R = ResT; y.ldr = ldt_; y.nrhs = nr;
+      for (int step = 0; step < refine_steps; ++step) {
+        NK_TRY(launch_resid_dd(ctx, Xq, mq, Pq, mq, Rq, mq, Res, mq, nr, mq));                    // Res = R - X P
+        NK_TRY(launch_transpose(ctx, Res, mq, ResT, ldt_, nr, mq));                               // columns for the solve
+        NK_TRY(cholesky_solve_pair(ctx, &y, 1));                                                  // P dX^T = Res^T
+        NK_TRY(launch_transpose(ctx, ResT, ldt_, Res, mq, mq, nr));
+        // X += dX while the corrections contract (a numerically singular system that happened to factor is left alone)
+        NK_TRY(launch_refine_apply(ctx, Res, mq, Xq, mq, nr, mq, step, refine_state + 4 * q, partial));
+      }
+      NK_HIP(hipMemcpyAsync(ctx->h_scalars + 16 + 4 * q, refine_state + 4 * q, 4 * sizeof(double), hipMemcpyDeviceToHost,
+                            ctx->stream));
+      arena_release(ctx, mk);
+      refined[q] = -1;  // verdict in h_scalars[16 + 4 q ..] after the synchronisation below
+      redo_products = true;
+    }
+  }
   {
     const int vr = sqrtm_verdict(ctx, &splan, &it, &resid);  // the iteration was queued without host round trips
     if (vr == NK_SQRT_RETRY) {
@@ -1358,6 +1428,13 @@ static int fit_impl(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int6
     NK_TRY(operator_products());
     NK_HIP(hipStreamSynchronize(ctx->stream));
   }
+  double refine_ratio[2] = {0.0, 0.0};
+  for (int q = 0; q < 2; ++q)
+    if (refined[q] < 0) {
+      refined[q] = (int)ctx->h_scalars[16 + 4 * q + 2];  // steps accepted by the contraction guard
+      refine_ratio[q] = ctx->h_scalars[16 + 4 * q + 3];
+    }
+  if (refined[0] > 0 || refined[1] > 0) count_event(CNT_REFINED);
   mdl->has_ops = true;
 
   if (stats) {
@@ -1383,6 +1460,11 @@ static int fit_impl(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int6
     stats->kmat_pairs = 2.0 * ne * m * d + (same_centers ? 1.0 : 3.0) * (double)m * m * d;
     stats->rank_inner = rank_sys[0];
     stats->rank_inner_rec = rank_sys[1];
+    stats->pivot_ratio_inner = piv_ratio[0];
+    stats->pivot_ratio_inner_rec = piv_ratio[1];
+    stats->refined = refined[0] + 16 * refined[1];
+    stats->refine_ratio_inner = refine_ratio[0];
+    stats->refine_ratio_inner_rec = refine_ratio[1];
   }
   tr.mark("stats");
   if (ctx->arena.chunks.size() > 1 || ctx->arena_side.chunks.size() > 1) NK_TRY(arena_reset(ctx));  // coalesce now (everything is synchronised), not in the next call
@@ -2105,7 +2187,7 @@ int nk_solve_spd(nk_ctx* ctx, const double* P, int64_t ldp, int32_t m, const dou
   const int nblk = (m + CHOL_NB - 1) / CHOL_NB;
   const int64_t ldw = nrhs + (nrhs & 1);
   NK_TRY(arena_alloc_t(ctx, (size_t)m * m, &L));
-  NK_TRY(arena_alloc_t(ctx, (size_t)nblk * CHOL_NB * CHOL_NB, &Linv));
+  NK_TRY(arena_alloc_t(ctx, (size_t)nblk * CHOL_WS, &Linv));
   NK_TRY(arena_alloc_t(ctx, (size_t)m * ldw, &W));
   NK_TRY(launch_copy2d(ctx, p.ptr, p.ld, L, m, m, m));
   NK_TRY(launch_copy2d(ctx, r.ptr, r.ld, W, ldw, m, nrhs));

@@ -83,6 +83,10 @@ struct nk_ctx {
   hipEvent_t ev[16];
   int num_cu = 256;
   int kmat_mode = 0;  // 0 auto (Gram form on MFMA for d >= 32), 1 always direct differences (NYSKOOP_KMAT=direct)
+  // optional refinement of the two regularised solves with doubled-precision residuals (nk_set_refine): applied to a system
+  // whose smallest / largest Cholesky pivot is below refine_pivot (0 = never, the default), refine_steps steps
+  double refine_pivot = 0.0;
+  int refine_steps = 2;
   int strict_spd = 0; // 1: a non-positive Cholesky pivot is an error (NK_ERR_NOT_SPD) instead of entering the
                       // rank-truncating pseudo-inverse path (NYSKOOP_STRICT_SPD=1 / nk_set_strict_spd)
   hipEvent_t ev_ext = nullptr;  // ordering against a caller's stream (nk_wait_stream)
@@ -137,7 +141,7 @@ int group_enter(nk_ctx* c);
 int group_leave(nk_ctx* c);
 void group_stats(nk_ctx* c, uint64_t out[4]);
 // slow-path counters (nk_runtime_counters)
-enum { CNT_CHAIN_GIVEUP = 0, CNT_JACOBI_GIVEUP = 1, CNT_RANK_TRUNCATED = 2, CNT_SQRT_RETRY = 3, CNT_N = 4 };
+enum { CNT_CHAIN_GIVEUP = 0, CNT_JACOBI_GIVEUP = 1, CNT_RANK_TRUNCATED = 2, CNT_SQRT_RETRY = 3, CNT_REFINED = 4, CNT_N = 5 };
 void count_event(int which);
 uint64_t read_counter(int which);
 hipError_t real_stream_sync(hipStream_t s);
@@ -264,6 +268,21 @@ int cholesky_solve_pair(nk_ctx* ctx, const CholSys* sys, int nsys);
 // pause / pause_step: before block step pause_step the chain's stream waits for the (already recorded) event `pause`
 int cholesky_aug_pair_async(nk_ctx* ctx, const CholSys* sys, int nsys, hipEvent_t pause = nullptr, int pause_step = -1);
 constexpr int CHOL_NB = 64;
+// workspace per diagonal block of a blocked factorisation (CholSys::Linv): the inverted 64 x 64 diagonal block of the factor
+// followed by the diagonal block itself, both dense row-major with exact zeros above the diagonal and identity padding
+// beyond a short last block.  The factor rides along because every product with the explicit inverse is followed by one
+// correction step  x += (b - x L_jj) L_jj^-1  (see chol_panel_kernel): multiplying by an explicit inverse alone is not
+// backward stable -- its error grows with cond(L_jj), 1e6 on the kernel matrices here.
+constexpr int CHOL_WS = 2 * CHOL_NB * CHOL_NB + 8;  // (+ one verdict word, padded to 64 bytes)
+// the verdict word behind the two blocks: 1.0 when ||L_jj||_F ||L_jj^-1||_F exceeds this and the products with the inverse
+// take the correction step (potrf_diag_kernel)
+constexpr double CHOL_FIX_KAPPA = 8.0 * CHOL_NB;
+// NYSKOOP_CHOL_FIX (read per launch: same-process A/B; for measurements only): 0 = never correct, 2 = always, default 1 = where
+// the verdict word says so
+inline int chol_fix_enabled() {
+  const char* e = getenv("NYSKOOP_CHOL_FIX");
+  return (e && e[0] == '0') ? 0 : ((e && e[0] == '2') ? 2 : 1);
+}
 // trailing update C -= P P^T (K = 64) of up to two systems (nk_trail.hip); false: not that shape, use launch_gemm_pair
 bool launch_chol_trail_pair(nk_ctx* ctx, const GemmCall* calls, int ncalls, int* rc);
 // panel product P <- P Linv_jj^T (64 x 64) of up to two systems (nk_trail.hip); false: not that shape
@@ -281,7 +300,8 @@ struct PinvInfo {
 int pinv_right_divide(nk_ctx* ctx, const double* P, int64_t ldp, int m, const double* E, int64_t lde, int rows,
                       double* E_out, int64_t ldeo, double rcond, PinvInfo* info);
 // which systems of the last (paired) factorisation on the current stream met a non-positive pivot (synchronises)
-int cholesky_fail_flags(nk_ctx* ctx, const CholSys* sys, int nsys, int* failed /* nsys entries */);
+// piv_ratio (optional, nsys entries): smallest / largest pivot of each factorisation (0 when it failed)
+int cholesky_fail_flags(nk_ctx* ctx, const CholSys* sys, int nsys, int* failed /* nsys entries */, double* piv_ratio = nullptr);
 
 // matrix-vector step of the lifted recursion for up to 8 trajectories (nk_rollout.hip)
 int launch_lifted_step(nk_ctx* ctx, const double* G, int64_t ldg, int m, int mz, int pu, const double* z, int64_t zstride,
@@ -372,6 +392,14 @@ int launch_kmat_gram_f32(nk_ctx* ctx, int ktype, const float* At, int64_t ldat, 
 int launch_gemm_tn_multi(nk_ctx* ctx, const TnProblem* probs, int nprob, int64_t K, int splitk /*0=auto*/,
                          float* ms_kernel = nullptr, bool sync_timing = true, const TnSkip* skip = nullptr);
 int launch_transpose(nk_ctx* ctx, const double* src, int64_t lds, double* dst, int64_t ldd, int rows, int cols);
+// X += dX if the refinement still contracts (verdict on the device, in state[4]: alive, |dX|^2 last accepted, accepted
+// steps, |dX_0| / |X|); no host synchronisation
+constexpr int refine_partial_blocks() { return 512; }
+int launch_refine_apply(nk_ctx* ctx, const double* dX, int64_t ldd, double* X, int64_t ldx, int64_t rows, int64_t cols, int step,
+                        double* state, double* partial);
+// Res (nr x mq) = R - X P, dot products in doubled precision (compensated): the residual of the refinement steps
+int launch_resid_dd(nk_ctx* ctx, const double* X, int64_t ldx, const double* P, int64_t ldp, const double* R, int64_t ldr,
+                    double* Res, int64_t ldres, int nr, int mq);
 // Gram-form kernel matrix on the MFMA engine (nk_gemm_tn.hip): prep_rows centres/scales/transposes rows to
 // contraction-major and returns their squared norms; launch_kmat_gram evaluates k() in the GEMM epilogue
 int launch_colmean(nk_ctx* ctx, const double* Z, int64_t ldz, int rows, int d, double* mean);

@@ -183,6 +183,134 @@ __device__ __forceinline__ void colsum_finish_kernel_body(const double* __restri
 __global__ void __launch_bounds__(256) colsum_finish_kernel(const double* __restrict__ partial, int nslabs, int cols, double* __restrict__ colsum) { colsum_finish_kernel_body(partial, nslabs, cols, colsum); }
 NK_BATCHED_TWIN(colsum_finish_kernel, (256), const double*, int, int, double*)
 
+// Res (nr x mq) = R - X P with every dot product accumulated in DOUBLED precision (Ogita / Rump / Oishi's Dot2: the exact
+// product by an fma, the exact sum by Knuth's TwoSum, the error terms summed aside): the residual of the refinement step of
+// the regularised solves.  A residual formed in plain fp64 carries a rounding error of eps |X| |P| -- as large as the
+// residual itself, and the "correction" solved from it moves the solution AWAY from the true one (measured, also with
+// LAPACK's factor in NumPy: the cloth fixture's A goes from 4e-5 to 2e-3 off the reference); with the doubled-precision
+// residual each step contracts the forward error by cond(P) x the factor's backward error.  10 flop per term on the vector
+// ALU: 0.1 ms at m = 200, ~4 ms at m = 2000 -- paid only by fits whose pivots say they need it.
+__device__ __forceinline__ void resid_dd_kernel_body(const double* __restrict__ X, int64_t ldx, const double* __restrict__ P,
+                                                     int64_t ldp, const double* __restrict__ R, int64_t ldr,
+                                                     double* __restrict__ Res, int64_t ldres, int nr, int mq) {
+#pragma clang fp contract(off)  // the error-free transformations below need the product and the sum rounded separately
+  constexpr int T = 64, BK = 16;
+  __shared__ double Xs[T][BK + 1];
+  __shared__ double Ps[BK][T + 1];
+  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  const int i0 = blockIdx.y * T, j0 = blockIdx.x * T;
+  double s[4][4], e[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int i = i0 + ty + 16 * a, j = j0 + tx + 16 * b;
+      s[a][b] = (i < nr && j < mq) ? R[(int64_t)i * ldr + j] : 0.0;
+      e[a][b] = 0.0;
+    }
+  for (int k0 = 0; k0 < mq; k0 += BK) {
+#pragma unroll
+    for (int t = tid; t < T * BK; t += 256) {
+      const int ii = t / BK, kk = t % BK;   // X tile: k fastest (rows of X are contiguous in k)
+      const int i = i0 + ii, k = k0 + kk;
+      Xs[ii][kk] = (i < nr && k < mq) ? -X[(int64_t)i * ldx + k] : 0.0;
+      const int kq = t / T, jj = t % T;     // P tile: j fastest
+      const int kp = k0 + kq, j = j0 + jj;
+      Ps[kq][jj] = (kp < mq && j < mq) ? P[(int64_t)kp * ldp + j] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int kk = 0; kk < BK; ++kk) {
+      double xv[4], pv[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) xv[a] = Xs[ty + 16 * a][kk];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) pv[b] = Ps[kk][tx + 16 * b];
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const double h = xv[a] * pv[b];
+          const double r = __builtin_fma(xv[a], pv[b], -h);  // x y = h + r exactly
+          const double t = s[a][b] + h;                       // s + h = t + q exactly (TwoSum)
+          const double z = t - s[a][b];
+          const double q = (s[a][b] - (t - z)) + (h - z);
+          s[a][b] = t;
+          e[a][b] += q + r;
+        }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int i = i0 + ty + 16 * a, j = j0 + tx + 16 * b;
+      if (i < nr && j < mq) Res[(int64_t)i * ldres + j] = s[a][b] + e[a][b];
+    }
+}
+__global__ void __launch_bounds__(256) resid_dd_kernel(const double* __restrict__ X, int64_t ldx, const double* __restrict__ P, int64_t ldp, const double* __restrict__ R, int64_t ldr, double* __restrict__ Res, int64_t ldres, int nr, int mq) { resid_dd_kernel_body(X, ldx, P, ldp, R, ldr, Res, ldres, nr, mq); }
+NK_BATCHED_TWIN(resid_dd_kernel, (256), const double*, int64_t, const double*, int64_t, const double*, int64_t, double*, int64_t, int, int)
+
+// Guard of the refinement steps: a step is applied only while the corrections contract.  Per-block partial sums of squares of
+// the correction dX and of the solution X (rows x cols each) ...
+__device__ __forceinline__ void refine_norms_partial_kernel_body(const double* __restrict__ dX, int64_t ldd, const double* __restrict__ X, int64_t ldx, int64_t rows, int64_t cols, double* __restrict__ partial, int nblocks) {
+  __shared__ double sh[8];
+  const int64_t total = rows * cols;
+  double s = 0.0, t = 0.0;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = e / cols, c = e - r * cols;
+    const double v = dX[r * ldd + c], w = X[r * ldx + c];
+    s = fma(v, v, s);
+    t = fma(w, w, t);
+  }
+  s = wave_sum(s);
+  t = wave_sum(t);
+  if ((threadIdx.x & 63) == 0) { sh[threadIdx.x >> 6] = s; sh[4 + (threadIdx.x >> 6)] = t; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partial[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+    partial[nblocks + blockIdx.x] = sh[4] + sh[5] + sh[6] + sh[7];
+  }
+}
+__global__ void __launch_bounds__(256) refine_norms_partial_kernel(const double* __restrict__ dX, int64_t ldd, const double* __restrict__ X, int64_t ldx, int64_t rows, int64_t cols, double* __restrict__ partial, int nblocks) { refine_norms_partial_kernel_body(dX, ldd, X, ldx, rows, cols, partial, nblocks); }
+NK_BATCHED_TWIN(refine_norms_partial_kernel, (256), const double*, int64_t, const double*, int64_t, int64_t, int64_t, double*, int)
+// ... and the verdict (one block).  state = [alive, |dX|^2 of the last accepted step, accepted steps, |dX_0| / |X|].  Step 0 is
+// accepted when |dX_0| <= |X| / 4 -- the ratio estimates cond x (backward error of the factor), the contraction per step; a
+// numerically singular system that happened to factor (gelsd would truncate it) gives >= 1 here and is left alone -- and a
+// later step when its correction is at most half the previous one.  Once a step is rejected all later ones are.
+__device__ __forceinline__ void refine_gate_kernel_body(const double* __restrict__ partial, int nblocks, int step, double* __restrict__ state) {
+  __shared__ double sh[8];
+  double s = 0.0, t = 0.0;
+  for (int i = threadIdx.x; i < nblocks; i += blockDim.x) { s += partial[i]; t += partial[nblocks + i]; }
+  s = wave_sum(s);
+  t = wave_sum(t);
+  if ((threadIdx.x & 63) == 0) { sh[threadIdx.x >> 6] = s; sh[4 + (threadIdx.x >> 6)] = t; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double dx2 = sh[0] + sh[1] + sh[2] + sh[3], x2 = sh[4] + sh[5] + sh[6] + sh[7];
+    const bool alive = step == 0 ? true : state[0] != 0.0;
+    const double ref2 = step == 0 ? 0.0625 * x2 : 0.25 * state[1];
+    const bool ok = alive && dx2 <= ref2;  // false for NaN
+    state[0] = ok ? 1.0 : 0.0;
+    if (ok) state[1] = dx2;
+    state[2] = (step == 0 ? 0.0 : state[2]) + (ok ? 1.0 : 0.0);
+    if (step == 0) state[3] = x2 > 0.0 ? sqrt(dx2 / x2) : 0.0;
+  }
+}
+__global__ void __launch_bounds__(256) refine_gate_kernel(const double* __restrict__ partial, int nblocks, int step, double* __restrict__ state) { refine_gate_kernel_body(partial, nblocks, step, state); }
+NK_BATCHED_TWIN(refine_gate_kernel, (256), const double*, int, int, double*)
+__device__ __forceinline__ void guarded_add_kernel_body(const double* __restrict__ dX, int64_t ldd, double* __restrict__ X, int64_t ldx, int64_t rows, int64_t cols, const double* __restrict__ state) {
+  if (state[0] == 0.0) return;
+  const int64_t total = rows * cols;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = e / cols, c = e - r * cols;
+    X[r * ldx + c] += dX[r * ldd + c];
+  }
+}
+__global__ void __launch_bounds__(256) guarded_add_kernel(const double* __restrict__ dX, int64_t ldd, double* __restrict__ X, int64_t ldx, int64_t rows, int64_t cols, const double* __restrict__ state) { guarded_add_kernel_body(dX, ldd, X, ldx, rows, cols, state); }
+NK_BATCHED_TWIN(guarded_add_kernel, (256), const double*, int64_t, double*, int64_t, int64_t, int64_t, const double*)
+
 static inline int grid_for(int64_t total, int num_cu) {
   int64_t b = (total + 255) / 256;
   const int64_t cap = (int64_t)num_cu * 8;
@@ -207,6 +335,26 @@ int launch_axpby2d(nk_ctx* ctx, double a, const double* X, int64_t ldx, double b
   if (rows <= 0 || cols <= 0) return NK_OK;
   hipLaunchKernelGGL(axpby2d_kernel, dim3(grid_for(rows * cols, ctx->num_cu)), dim3(256), 0, ctx->stream, a, X, ldx, b,
                      Y, ldy, rows, cols);
+  NK_HIP(hipGetLastError());
+  return NK_OK;
+}
+int launch_resid_dd(nk_ctx* ctx, const double* X, int64_t ldx, const double* P, int64_t ldp, const double* R, int64_t ldr,
+                    double* Res, int64_t ldres, int nr, int mq) {
+  if (nr <= 0 || mq <= 0) return NK_OK;
+  hipLaunchKernelGGL(resid_dd_kernel, dim3((mq + 63) / 64, (nr + 63) / 64), dim3(256), 0, ctx->stream, X, ldx, P, ldp, R,
+                     ldr, Res, ldres, nr, mq);
+  NK_HIP(hipGetLastError());
+  return NK_OK;
+}
+int launch_refine_apply(nk_ctx* ctx, const double* dX, int64_t ldd, double* X, int64_t ldx, int64_t rows, int64_t cols, int step,
+                        double* state, double* partial /* 2 * refine_partial_blocks() doubles */) {
+  if (rows <= 0 || cols <= 0) return NK_OK;
+  const int blocks = std::min(grid_for(rows * cols, ctx->num_cu), refine_partial_blocks());
+  hipLaunchKernelGGL(refine_norms_partial_kernel, dim3(blocks), dim3(256), 0, ctx->stream, dX, ldd, (const double*)X, ldx, rows,
+                     cols, partial, blocks);
+  hipLaunchKernelGGL(refine_gate_kernel, dim3(1), dim3(256), 0, ctx->stream, (const double*)partial, blocks, step, state);
+  hipLaunchKernelGGL(guarded_add_kernel, dim3(grid_for(rows * cols, ctx->num_cu)), dim3(256), 0, ctx->stream, dX, ldd, X, ldx,
+                     rows, cols, (const double*)state);
   NK_HIP(hipGetLastError());
   return NK_OK;
 }
@@ -460,7 +608,7 @@ int cholesky_lower_pair_async(nk_ctx* ctx, const CholSys* sys, int nsys) {
       nbj[q] = y.m - j0 < NB ? y.m - j0 : NB;
       Ajj[q] = y.P + (int64_t)j0 * y.ldp + j0;
       lda[q] = y.ldp;
-      Li[q] = y.Linv + (size_t)jb * NB * NB;
+      Li[q] = y.Linv + (size_t)jb * CHOL_WS;
       Pl[q] = y.pivlog ? y.pivlog + j0 : nullptr;
       const int rem = y.m - j0 - nbj[q];
       if (rem > 0) {
@@ -516,7 +664,7 @@ int cholesky_check_pair(nk_ctx* ctx, const CholSys* sys, int nsys) {
 // a hyper-parameter grid: genuine pivots of 1e-13 d_max across the whole gamma = 1e-7 row of the cloth grid -- has no such
 // gap and is solved at full rank: there the reference's own rank decision is rounding noise and the
 // SVD path would cost 100 x more for an answer no closer to it.  Synchronises the current stream.
-int cholesky_fail_flags(nk_ctx* ctx, const CholSys* sys, int nsys, int* failed) {
+int cholesky_fail_flags(nk_ctx* ctx, const CholSys* sys, int nsys, int* failed, double* piv_ratio) {
   const int ib = info_base(ctx);
   std::vector<double> plog[2];
   NK_HIP(hipMemcpyAsync(ctx->h_info + ib, ctx->d_info + ib, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
@@ -531,11 +679,13 @@ int cholesky_fail_flags(nk_ctx* ctx, const CholSys* sys, int nsys, int* failed) 
   const double eps = 2.220446049250313e-16;
   for (int q = 0; q < nsys; ++q) {
     failed[q] = ctx->h_info[ib + q];
+    if (piv_ratio) piv_ratio[q] = 0.0;
     if (failed[q] != 0) continue;
     double dmin, dmax;
     memcpy(&dmin, &ctx->h_piv[2 * (ib + q)], 8);
     memcpy(&dmax, &ctx->h_piv[2 * (ib + q) + 1], 8);
     if (!(dmax > 0.0)) continue;
+    if (piv_ratio) piv_ratio[q] = dmin / dmax;
     if (dmin <= eps * dmax) { failed[q] = -1; continue; }
     if (plog[q].empty()) continue;
     std::sort(plog[q].begin(), plog[q].end());
@@ -604,7 +754,7 @@ int cholesky_aug_pair_async(nk_ctx* ctx, const CholSys* sys, int nsys, hipEvent_
       nbj[q] = y.m - j0 < NB ? y.m - j0 : NB;
       Ajj[q] = y.P + (int64_t)j0 * y.ldp + j0;
       lda[q] = y.ldp;
-      Li[q] = y.Linv + (size_t)jb * NB * NB;
+      Li[q] = y.Linv + (size_t)jb * CHOL_WS;
       Pl[q] = y.pivlog ? y.pivlog + j0 : nullptr;
       const int rem = y.m - j0 - nbj[q];      // rows of the square part below the diagonal block
       const int rows = rem + y.extra;         // ... plus the right-hand-side rows
@@ -674,18 +824,42 @@ int cholesky_solve_pair(nk_ctx* ctx, const CholSys* sys, int nsys) {
   NK_REQUIRE(nsys >= 1 && nsys <= 2, "cholesky_solve_pair: 1..2 systems");
   int nblk = 0;
   for (int q = 0; q < nsys; ++q) nblk = std::max(nblk, (sys[q].m + NB - 1) / NB);
-  // forward: L T = R
-  for (int jb = 0; jb < nblk; ++jb) {
+  const ArenaMark mk = arena_mark(ctx);
+  double* tmp[2] = {nullptr, nullptr};
+  for (int q = 0; q < nsys; ++q) NK_TRY(arena_alloc_t(ctx, (size_t)NB * sys[q].ldr, &tmp[q]));
+  // One diagonal-block solve  R_j <- op(L_jj)^-1 R_j : the product with the explicitly inverted block, then one correction
+  // step from the data (the product alone is not backward stable, see chol_panel_kernel):
+  //   X = Linv R_j ;  X += Linv (R_j - L_jj X)
+  auto diag_solve = [&](int jb, bool trans) -> int {
     const int j0 = jb * NB;
-    GemmCall diag[2], upd[2];
+    GemmCall g1[2], g2[2], g3[2];
     for (int q = 0; q < nsys; ++q) {
       const CholSys& y = sys[q];
       if (j0 >= y.m) continue;
       const int nbj = y.m - j0 < NB ? y.m - j0 : NB;
-      const double* Li = y.Linv + (size_t)jb * NB * NB;
+      const double* Li = y.Linv + (size_t)jb * CHOL_WS;
+      const double* Ld = Li + NB * NB;
       double* Rj = y.R + (int64_t)j0 * y.ldr;
-      diag[q].M = nbj; diag[q].N = y.nrhs; diag[q].K = nbj; diag[q].A = Li; diag[q].lda = NB; diag[q].B = Rj;
-      diag[q].ldb = y.ldr; diag[q].C = Rj; diag[q].ldc = y.ldr;
+      NK_TRY(launch_copy2d(ctx, Rj, y.ldr, tmp[q], y.ldr, nbj, y.nrhs));
+      g1[q].M = nbj; g1[q].N = y.nrhs; g1[q].K = nbj; g1[q].A = Li; g1[q].lda = NB; g1[q].B = tmp[q]; g1[q].ldb = y.ldr;
+      g1[q].C = Rj; g1[q].ldc = y.ldr;
+      g2[q] = g1[q]; g2[q].A = Ld; g2[q].B = Rj; g2[q].C = tmp[q]; g2[q].alpha = -1.0; g2[q].beta = 1.0;
+      g3[q] = g1[q]; g3[q].beta = 1.0;
+    }
+    NK_TRY(launch_gemm_pair(ctx, trans, false, g1, nsys));
+    NK_TRY(launch_gemm_pair(ctx, trans, false, g2, nsys));
+    NK_TRY(launch_gemm_pair(ctx, trans, false, g3, nsys));
+    return NK_OK;
+  };
+  // forward: L T = R
+  for (int jb = 0; jb < nblk; ++jb) {
+    const int j0 = jb * NB;
+    GemmCall upd[2];
+    for (int q = 0; q < nsys; ++q) {
+      const CholSys& y = sys[q];
+      if (j0 >= y.m) continue;
+      const int nbj = y.m - j0 < NB ? y.m - j0 : NB;
+      double* Rj = y.R + (int64_t)j0 * y.ldr;
       const int rem = y.m - j0 - nbj;
       if (rem > 0) {
         upd[q].M = rem; upd[q].N = y.nrhs; upd[q].K = nbj; upd[q].alpha = -1.0; upd[q].beta = 1.0;
@@ -693,30 +867,28 @@ int cholesky_solve_pair(nk_ctx* ctx, const CholSys* sys, int nsys) {
         upd[q].C = y.R + (int64_t)(j0 + nbj) * y.ldr; upd[q].ldc = y.ldr;
       }
     }
-    NK_TRY(launch_gemm_pair(ctx, false, false, diag, nsys));
+    NK_TRY(diag_solve(jb, false));
     NK_TRY(launch_gemm_pair(ctx, false, false, upd, nsys));
   }
   // backward: L^T X = T
   for (int jb = nblk - 1; jb >= 0; --jb) {
     const int j0 = jb * NB;
-    GemmCall diag[2], upd[2];
+    GemmCall upd[2];
     for (int q = 0; q < nsys; ++q) {
       const CholSys& y = sys[q];
       if (j0 >= y.m) continue;
       const int nbj = y.m - j0 < NB ? y.m - j0 : NB;
-      const double* Li = y.Linv + (size_t)jb * NB * NB;
       double* Rj = y.R + (int64_t)j0 * y.ldr;
-      diag[q].M = nbj; diag[q].N = y.nrhs; diag[q].K = nbj; diag[q].A = Li; diag[q].lda = NB; diag[q].B = Rj;
-      diag[q].ldb = y.ldr; diag[q].C = Rj; diag[q].ldc = y.ldr;
       if (j0 > 0) {
         upd[q].M = j0; upd[q].N = y.nrhs; upd[q].K = nbj; upd[q].alpha = -1.0; upd[q].beta = 1.0;
         upd[q].A = y.P + (int64_t)j0 * y.ldp; upd[q].lda = y.ldp; upd[q].B = Rj; upd[q].ldb = y.ldr;
         upd[q].C = y.R; upd[q].ldc = y.ldr;
       }
     }
-    NK_TRY(launch_gemm_pair(ctx, true, false, diag, nsys));
+    NK_TRY(diag_solve(jb, true));
     NK_TRY(launch_gemm_pair(ctx, true, false, upd, nsys));
   }
+  arena_release(ctx, mk);
   return NK_OK;
 }
 
@@ -773,7 +945,7 @@ int sqrtm_prepare(nk_ctx* ctx, const double* P, int64_t ldp, int m, SqrtPlan* pl
   const size_t mm = (size_t)m * m;
   const int nblk = (m + CHOL_NB - 1) / CHOL_NB;
   NK_TRY(arena_alloc_t(ctx, 2 * mm, &plan->W));
-  NK_TRY(arena_alloc_t(ctx, (size_t)nblk * CHOL_NB * CHOL_NB, &plan->Linv));
+  NK_TRY(arena_alloc_t(ctx, (size_t)nblk * CHOL_WS, &plan->Linv));
   NK_TRY(arena_alloc_t(ctx, mm, &plan->X0));
   NK_TRY(arena_alloc_t(ctx, mm, &plan->X0t));
   NK_TRY(arena_alloc_t(ctx, (size_t)8, &plan->d_sc));

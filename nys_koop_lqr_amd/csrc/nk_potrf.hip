@@ -213,6 +213,27 @@ __device__ __forceinline__ void potrf_diag_kernel_body(const PotrfBatch& pb, int
   // dense 64 x 64 row-major inverse, exact zeros above the block diagonal
 #pragma unroll 8
   for (int i = 0; i < NB; ++i) Linv[i * NB + lane] = (l4 <= (i >> 4)) ? Iv[i * PLD + lane] : 0.0;
+  // ... followed by the factor block itself in the same dense form (CHOL_WS): the correction step of every product with the
+  // inverse reads it (the copy in the matrix carries whatever the upper triangle held)
+  // ... and by the verdict whether products with this inverse need the correction step at all: the error of such a product
+  // grows with cond(L_jj) <= ||L_jj||_F ||L_jj^-1||_F.  Most diagonal blocks of a regularised kernel system are nearly
+  // scalar (at the headline shape 62 of 64 have ||.||_F ||.||_F / 64 < 2.2; the first and the last, which holds the input
+  // columns, 40 and 1000), so the correction runs where it is needed: above 8 x 64 (CHOL_FIX_KAPPA).
+  double sl = 0.0, si = 0.0;
+#pragma unroll 8
+  for (int i = 0; i < NB; ++i) {
+    const double vl = (lane <= i) ? As[i * PLD + lane] : 0.0;
+    const double vi = (l4 <= (i >> 4)) ? Iv[i * PLD + lane] : 0.0;
+    Linv[NB * NB + i * NB + lane] = vl;
+    sl = fma(vl, vl, sl);
+    si = fma(vi, vi, si);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    sl += __shfl_xor(sl, off, 64);
+    si += __shfl_xor(si, off, 64);
+  }
+  if (lane == 0) Linv[2 * NB * NB] = (sl * si > CHOL_FIX_KAPPA * CHOL_FIX_KAPPA) ? 1.0 : 0.0;  // NaN -> 0: a failed block
   if (lane == 0 && piv_max > 0.0) {
     atomicMin(pb.piv[which], (unsigned long long)__double_as_longlong(piv_min));
     atomicMax(pb.piv[which] + 1, (unsigned long long)__double_as_longlong(piv_max));

@@ -129,14 +129,29 @@ bool launch_chol_trail_pair(nk_ctx* ctx, const GemmCall* calls, int ncalls, int*
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Panel product of the same step:  P <- P Linv_jj^T  (rows x 64 times 64 x 64, in place: a workgroup reads exactly the
-// 128 rows it writes, and only after all of them have been read).  Same register-only scheme as the trailing update.
+// Panel solve of the same step:  P <- P L_jj^-T  (rows x 64 against the 64 x 64 diagonal block; in place: a workgroup reads
+// exactly the 64 rows it writes, and only after all of them have been read).  Register-only like the trailing update.
+//
+// The product with the explicitly inverted block, P1 = P Linv^T, is what makes this step a GEMM -- and on its own it is not
+// backward stable: its error grows with cond(L_jj) (2e6 on the first block of config 2's system), and through it the whole
+// blocked solve carried a backward error of 6 eps where LAPACK's substitution leaves 0.3 eps (tools/illcond_diag.py; the
+// same numbers from a NumPy emulation of this algorithm).  One correction step from the DATA restores it,
+//     P2 = P1 + (P - P1 L_jj^T) Linv^T,
+// three 64-wide products instead of one.  All three run on the matrix pipe in the TRANSPOSED form (D = Linv P^T: output
+// column = panel row), because in that form the accumulator of one product is, register for register, the b-operand of the
+// next: lane (l15, l4) of an accumulator holds P1[r(l15)][4 t + l4], t = 4 j + reg, and with the contraction index dealt as
+// k = 4 t + l4 that is exactly the b-operand of instruction t -- no LDS, no lane exchange.  The raw panel rows are loaded in
+// the same dealing and serve both as b-operand of the first product and as the minuend of the residual.
+// Columns beyond `nb` (a short last block; only the right-hand-side rows of an augmented system get there) are masked.
 // ---------------------------------------------------------------------------------------------------------------
+constexpr int PANEL_ROWS = 64;  // rows per workgroup of the panel solve
 struct PanelSys {
   double* P;
   int64_t ldp;
-  const double* Linv;  // 64 x 64, row-major, leading dimension 64
+  const double* Linv;  // CHOL_WS doubles: 64 x 64 inverse, then the 64 x 64 factor block (dense, identity padded)
   int rows;
+  int nb;              // valid columns of the block
+  int fix;             // correction step: 0 never, 1 where the block's verdict word says so, 2 always
   int nblocks;
 };
 struct PanelBatch {
@@ -150,56 +165,81 @@ __device__ __forceinline__ void chol_panel_kernel_body(const PanelBatch& pb) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int l15 = lane & 15, l4 = lane >> 4;
-  const int m0 = blockIdx.x * 128 + wave * 32;
-  d4 acc[2][4];
+  // 16 rows per wave, 64 per workgroup: the launch is latency bound (at most 63 workgroups on 256 CUs), so the rows are
+  // spread as thin as the 16-row matrix instruction allows
+  const int m0 = blockIdx.x * PANEL_ROWS + wave * 16;
+  const int nb = s.nb;
+  const double* __restrict__ Li = s.Linv;
+  const double* __restrict__ Ld = s.Linv + CHOL_NB * CHOL_NB;
+  // raw rows: a[t] = P[r][4 t + l4]
+  double a[16];
+  {
+    const double* pr = s.P + (int64_t)min(m0 + l15, s.rows - 1) * s.ldp + l4;
+    if (nb == CHOL_NB) {
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+      for (int t = 0; t < 16; ++t) a[t] = pr[4 * t];
+    } else {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
-  const double* pa[2];
-  const double* pl[4];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) pa[i] = s.P + (int64_t)min(m0 + 16 * i + l15, s.rows - 1) * s.ldp + 8 * l4;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) pl[j] = s.Linv + (16 * j + l15) * 64 + 8 * l4;  // output column c <-> row c of Linv
-  double a[2][2][8], b[2][4][8];  // both halves of K are loaded before anything is stored (in-place update)
-#pragma unroll
-  for (int h = 0; h < 2; ++h)
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i) a[h][i][ks] = pa[i][32 * h + ks];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) b[h][j][ks] = pl[j][32 * h + ks];
+      for (int t = 0; t < 16; ++t) a[t] = (4 * t + l4 < nb) ? pr[4 * t] : 0.0;
     }
+  }
+  // a-operands: rows of the inverse, k = 4 t + l4
+  double li[4][16];
 #pragma unroll
-  for (int h = 0; h < 2; ++h)
+  for (int j = 0; j < 4; ++j)
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks)
+    for (int t = 0; t < 16; ++t) li[j][t] = Li[(16 * j + l15) * CHOL_NB + 4 * t + l4];
+  // 1.  P1 = P Linv^T
+  // (t outer, j inner everywhere: four independent accumulator chains in flight -- a dependent fp64 matrix instruction waits
+  // ~200 cycles for its predecessor, three times its issue interval)
+  d4 p1[4];
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+  for (int j = 0; j < 4; ++j) p1[j] = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[h][i][ks], b[h][j][ks], acc[i][j], 0, 0, 0);
+  for (int t = 0; t < 16; ++t)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) p1[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(li[j][t], a[t], p1[j], 0, 0, 0);
+  if (s.fix == 2 || (s.fix == 1 && s.Linv[2 * CHOL_NB * CHOL_NB] != 0.0)) {  // (uniform: one word per block)
+    // 2.  Rsd = P - P1 L_jj^T   (a-operand: minus the rows of the factor block; the accumulator starts from the raw rows)
+    d4 rs[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) rs[j] = d4{a[4 * j], a[4 * j + 1], a[4 * j + 2], a[4 * j + 3]};
+#pragma unroll
+    for (int t = 0; t < 16; ++t)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        rs[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Ld[(16 * j + l15) * CHOL_NB + 4 * t + l4], p1[t >> 2][t & 3], rs[j], 0, 0, 0);
+    // 3.  P2 = P1 + Rsd Linv^T
+    d4 p2[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) p2[j] = p1[j];
+#pragma unroll
+    for (int t = 0; t < 16; ++t)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) p2[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(li[j][t], rs[t >> 2][t & 3], p2[j], 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) p1[j] = p2[j];
+  }
   // every wave of the workgroup must have its raw rows in registers before any wave overwrites (waves own disjoint
   // rows, so this is only needed against the clamped loads of the last, partial tile)
   __syncthreads();
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
+  const int row = m0 + l15;
+  if (row < s.rows) {
+    double* pw = s.P + (int64_t)row * s.ldp + l4;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        const int row = m0 + 16 * i + l4 + 4 * reg;
-        if (row < s.rows) s.P[(int64_t)row * s.ldp + 16 * j + l15] = acc[i][j][reg];
-      }
+      for (int reg = 0; reg < 4; ++reg)
+        if (nb == CHOL_NB || 16 * j + 4 * reg + l4 < nb) pw[16 * j + 4 * reg] = p1[j][reg];
+  }
 }
 __global__ void __launch_bounds__(256) chol_panel_kernel(PanelBatch pb) { chol_panel_kernel_body(pb); }
 __global__ void __launch_bounds__(256) chol_panel_kernel_batched(const nk::ArgPack<PanelBatch>* table) { chol_panel_kernel_body(table[blockIdx.z].v); }
 static nk::TwinReg chol_panel_kernel_twin_reg(reinterpret_cast<const void*>(static_cast<void (*)(PanelBatch)>(chol_panel_kernel)),
                                  reinterpret_cast<const void*>(chol_panel_kernel_batched), sizeof(nk::ArgPack<PanelBatch>), "chol_panel_kernel");
 
-// panel products of up to two systems; calls[q] as prepared for the generic engine (C = A in place, B = Linv_jj with
-// leading dimension 64, N = K = 64, alpha = 1, beta = 0).  false: not that shape.
+// panel solves of up to two systems; calls[q] as prepared for the generic engine (C = A in place, B = the block's CHOL_WS
+// workspace with leading dimension 64, N = K = valid columns <= 64, alpha = 1, beta = 0).  false: not that shape.
 bool launch_chol_panel_pair(nk_ctx* ctx, const GemmCall* calls, int ncalls, int* rc) {
   *rc = NK_OK;
   PanelBatch pb;
@@ -209,9 +249,9 @@ bool launch_chol_panel_pair(nk_ctx* ctx, const GemmCall* calls, int ncalls, int*
     t = PanelSys{};
     if (q >= ncalls || calls[q].M <= 0 || calls[q].N <= 0) continue;
     const GemmCall& c = calls[q];
-    if (c.K != 64 || c.N != 64 || c.A != c.C || c.lda != c.ldc || c.ldb != 64 || c.alpha != 1.0 || c.beta != 0.0) return false;
-    t.P = c.C; t.ldp = c.ldc; t.Linv = c.B; t.rows = (int)c.M;
-    t.nblocks = (t.rows + 127) / 128;
+    if (c.K != c.N || c.N > 64 || c.A != c.C || c.lda != c.ldc || c.ldb != 64 || c.alpha != 1.0 || c.beta != 0.0) return false;
+    t.P = c.C; t.ldp = c.ldc; t.Linv = c.B; t.rows = (int)c.M; t.nb = (int)c.N; t.fix = chol_fix_enabled();
+    t.nblocks = (t.rows + PANEL_ROWS - 1) / PANEL_ROWS;
     if (t.nblocks > maxblocks) maxblocks = t.nblocks;
   }
   if (maxblocks == 0) return true;

@@ -26,6 +26,7 @@ struct TrsmSys {
   int m;
   const double* Dinv;  // inverted 64 x 64 diagonal blocks, dense row-major, identity padded
   int wg_begin;        // first workgroup of this system
+  int fix;             // correction step of the diagonal-block solves: 0 never, 1 by the block's verdict word, 2 always
 };
 struct TrsmBatch {
   TrsmSys s[2];
@@ -46,6 +47,7 @@ __device__ __forceinline__ void trsm_right_lower_kernel_body(const TrsmBatch& tb
   __builtin_amdgcn_s_setprio(2);
   __shared__ double Xs[2][TR_ROWS * TLD];  // X_i band blocks (a-operand of the accumulation), double buffered
   __shared__ double T[TR_ROWS * TLD];      // accumulator on its way to becoming an a-operand
+  __shared__ double O[TR_ROWS * TLD];      // X_j before its correction step, likewise
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int l15 = lane & 15, l4 = lane >> 4;
@@ -148,16 +150,78 @@ __device__ __forceinline__ void trsm_right_lower_kernel_body(const TrsmBatch& tb
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) T[(16 * rt + l4 + 4 * reg) * TLD + 16 * w + l15] = col_ok ? acc[rt][reg] : 0.0;
     __syncthreads();
-    const double* __restrict__ D = s.Dinv + (size_t)j * NB * NB;
+    const double* __restrict__ D = s.Dinv + (size_t)j * CHOL_WS;
+    const double* __restrict__ Ld = D + NB * NB;  // the factor's diagonal block, dense (CHOL_WS)
     d4 out[TR_RT];
 #pragma unroll
     for (int rt = 0; rt < TR_RT; ++rt) out[rt] = d4{0.0, 0.0, 0.0, 0.0};
+    double bd[16];
 #pragma unroll
-    for (int ks = 0; ks < 16; ++ks) {
-      const double bd = -D[(4 * ks + l4) * NB + 16 * w + l15];  // X_j = -acc L_jj^-1
+    for (int ks = 0; ks < 16; ++ks) bd[ks] = -D[(4 * ks + l4) * NB + 16 * w + l15];  // X_j = -acc L_jj^-1
+    // (two accumulator chains per product below: a dependent fp64 matrix instruction waits ~200 cycles for its predecessor)
+    {
+      d4 o2[TR_RT];
+#pragma unroll
+      for (int rt = 0; rt < TR_RT; ++rt) o2[rt] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int ks = 0; ks < 16; ks += 2)
+#pragma unroll
+        for (int rt = 0; rt < TR_RT; ++rt) {
+          out[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(T[(16 * rt + l15) * TLD + 4 * ks + l4], bd[ks], out[rt], 0, 0, 0);
+          o2[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(T[(16 * rt + l15) * TLD + 4 * (ks + 1) + l4], bd[ks + 1], o2[rt], 0, 0, 0);
+        }
+#pragma unroll
+      for (int rt = 0; rt < TR_RT; ++rt) out[rt] += o2[rt];
+    }
+    // One correction step from the data (see chol_panel_kernel: the product with the explicit inverse alone is not backward
+    // stable):  U = acc + X_j L_jj  (the negated residual of X_j L_jj = -acc),  X_j <- X_j - U L_jj^-1.  X_j goes through LDS
+    // to become an a-operand; U takes the place of the accumulator image in T.
+    if (s.fix == 2 || (s.fix == 1 && D[2 * NB * NB] != 0.0)) {  // (uniform: one word per block)
+#pragma unroll
+    for (int rt = 0; rt < TR_RT; ++rt)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) O[(16 * rt + l4 + 4 * reg) * TLD + 16 * w + l15] = out[rt][reg];
+    __syncthreads();  // (also: every wave is done reading T)
+    {
+      d4 u[TR_RT];
 #pragma unroll
       for (int rt = 0; rt < TR_RT; ++rt)
-        out[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(T[(16 * rt + l15) * TLD + 4 * ks + l4], bd, out[rt], 0, 0, 0);
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) u[rt][reg] = col_ok ? acc[rt][reg] : 0.0;
+      d4 u2[TR_RT];
+#pragma unroll
+      for (int rt = 0; rt < TR_RT; ++rt) u2[rt] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int ks = 0; ks < 16; ks += 2) {
+        const double bl0 = Ld[(4 * ks + l4) * NB + 16 * w + l15], bl1 = Ld[(4 * (ks + 1) + l4) * NB + 16 * w + l15];
+#pragma unroll
+        for (int rt = 0; rt < TR_RT; ++rt) {
+          u[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(O[(16 * rt + l15) * TLD + 4 * ks + l4], bl0, u[rt], 0, 0, 0);
+          u2[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(O[(16 * rt + l15) * TLD + 4 * (ks + 1) + l4], bl1, u2[rt], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int rt = 0; rt < TR_RT; ++rt) u[rt] += u2[rt];
+#pragma unroll
+      for (int rt = 0; rt < TR_RT; ++rt)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) T[(16 * rt + l4 + 4 * reg) * TLD + 16 * w + l15] = u[rt][reg];
+    }
+    __syncthreads();
+    {
+      d4 o2[TR_RT];
+#pragma unroll
+      for (int rt = 0; rt < TR_RT; ++rt) o2[rt] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int ks = 0; ks < 16; ks += 2)
+#pragma unroll
+        for (int rt = 0; rt < TR_RT; ++rt) {
+          out[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(T[(16 * rt + l15) * TLD + 4 * ks + l4], bd[ks], out[rt], 0, 0, 0);
+          o2[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(T[(16 * rt + l15) * TLD + 4 * (ks + 1) + l4], bd[ks + 1], o2[rt], 0, 0, 0);
+        }
+#pragma unroll
+      for (int rt = 0; rt < TR_RT; ++rt) out[rt] += o2[rt];
+    }
     }
 #pragma unroll
     for (int rt = 0; rt < TR_RT; ++rt)
@@ -189,7 +253,7 @@ int launch_trsm_right_lower_pair(nk_ctx* ctx, const CholSys* sys, int nsys) {
     if (y.extra <= 0 || !y.backward) continue;
     TrsmSys& t = tb.s[tb.nsys++];
     t.E = y.P + (int64_t)y.m * y.ldp; t.lde = y.ldp; t.rows = y.extra;
-    t.L = y.P; t.ldl = y.ldp; t.m = y.m; t.Dinv = y.Linv; t.wg_begin = wgs;
+    t.L = y.P; t.ldl = y.ldp; t.m = y.m; t.Dinv = y.Linv; t.wg_begin = wgs; t.fix = chol_fix_enabled();
     wgs += (y.extra + TR_ROWS - 1) / TR_ROWS;
   }
   if (tb.nsys == 0) return NK_OK;

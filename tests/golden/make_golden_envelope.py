@@ -20,6 +20,7 @@ the rank-recording spy of make_golden_configs.py).
 
     python tests/golden/make_golden_envelope.py cloth     -> f7b_cloth_cv_envelope.npz   (405 units x 4 extra sweeps)
     python tests/golden/make_golden_envelope.py duffing   -> f12b_duffing_envelope.npz   (60 fits x 3 drivers)
+    python tests/golden/make_golden_envelope.py hjb       -> f8b_hjb_envelope.npz        (config 2: operators)
 """
 import os
 import random
@@ -178,6 +179,32 @@ def duffing():
     print("duffing envelope by m (max over seeds):", dict(zip(ms.tolist(), np.round(env.max(axis=0), 6).tolist())))
 
 
+def hjb():
+    """Config 2 (f8: HJB N = 1e4, m = 200, Matern-5/2): how far the reference's operators move with another LAPACK driver for
+    the two solves and with the samples in another row order (the 1e-15 input perturbation is already in f8)."""
+    g = np.load(f"{OUT}/f8_hjb_config2.npz")
+    X, Y, idx = g["X"], g["Y"], g["idx"]
+    ls, gamma, m = float(g["ls"]), float(g["gamma"]), int(g["m"])
+    relf = lambda a, b: float(np.linalg.norm(a - b) / np.linalg.norm(b))
+
+    def fit(Xs, Ys):
+        reg = R.KoopmanNystromRegressor(1, kernel=R.KernelWrapper([ls]), gamma=gamma, m=m)
+        reg.nystrom_centers_output = Y.T[:, idx]
+        reg.fit(Xs, Ys)
+        return np.array([relf(reg.A, g["A"]), relf(reg.B, g["B"]), relf(reg.C, g["C"]), relf(reg.weights, g["W"])])
+
+    env = np.zeros(4)
+    for mode in ("gelsy", "chol", "eigh"):
+        with LstsqSwap(mode):
+            dev = fit(X, Y)
+        print("hjb:", mode, "moves (A, B, C, W) by", dev, flush=True)
+        env = np.maximum(env, dev)
+    perm = np.random.default_rng(5).permutation(X.shape[0])
+    row = fit(np.ascontiguousarray(X[perm]), np.ascontiguousarray(Y[perm]))
+    print("hjb: another row order moves (A, B, C, W) by", row, "; 1e-15 input perturbation (f8):", float(g["op_sensitivity"]))
+    np.savez_compressed(f"{OUT}/f8b_hjb_envelope.npz", op_envelope=env, op_roworder=row)
+
+
 if __name__ == "__main__":
-    for a in sys.argv[1:] or ["duffing", "cloth"]:
-        {"cloth": cloth, "duffing": duffing}[a]()
+    for a in sys.argv[1:] or ["duffing", "cloth", "hjb"]:
+        {"cloth": cloth, "duffing": duffing, "hjb": hjb}[a]()

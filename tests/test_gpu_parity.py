@@ -145,8 +145,8 @@ FITS = [
     ("f1_cloth_rbf_wellcond.npz", 6, 1e-6, 1e-7),
     ("f2_synth_rbf_d384.npz", 6, 1e-8, 1e-9),
     ("f4_hjb_matern.npz", 1, 1e-6, 1e-7),
-    ("f1_cloth_rbf_illcond.npz", 6, 5e-3, 1e-4),
-    ("f3_duffing_matern.npz", 1, 5e-3, 1e-3),
+    ("f1_cloth_rbf_illcond.npz", 6, 5e-4, 1e-4),  # cond(inner) 1.6e13: measured 6e-5 (LAPACK's Cholesky in the reference: 4e-5)
+    ("f3_duffing_matern.npz", 1, 5e-4, 1e-3),     # cond(inner) 1.1e13: measured 2.5e-5
 ]
 
 

@@ -72,7 +72,7 @@ def test_runtime_counters_count_the_rank_truncating_branch(nk):
     reg.fit(X, Y)
     after = _lib.runtime_counters()
     assert after["rank_truncated_fits"] == before["rank_truncated_fits"] + 1
-    assert set(after) == {"chain_giveups", "jacobi_giveups", "rank_truncated_fits", "sqrt_retries"}
+    assert set(after) == {"chain_giveups", "jacobi_giveups", "rank_truncated_fits", "sqrt_retries", "refined_fits"}
 
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (2006, 2000, 1000), (384, 2000, 777), (130, 258, 17), (2, 2, 3),
@@ -169,3 +169,47 @@ dist.destroy_process_group()
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, (out.stdout[-300:], out.stderr[-2000:])
     assert "EQUAL True nccl" in out.stdout, out.stdout[-300:]
+
+
+def test_optional_refinement_with_doubled_precision_residuals(nk, golden):
+    """nk_set_refine: an ill-conditioned regularised system (config 2, cond 1.3e13) refined with residuals accumulated in
+    doubled precision -- the corrections contract (first one 4e-4 of the solution: the blocked solve is already backward
+    stable), both steps are applied to both systems, the operators stay within the reference's own reproducibility (f8b) and
+    move towards the reference; a well-conditioned fit is left alone; switched off again the bits are those of before."""
+    from nys_koop_lqr_amd import _lib
+    ctx = _lib.get_context()
+    g = golden("f8_hjb_config2.npz")
+    env = golden("f8b_hjb_envelope.npz")
+    X, Y, idx = g["X"], g["Y"], g["idx"]
+
+    def fit():
+        reg = nk.KoopmanNystromRegressor(1, kernel=nk.KernelWrapper([float(g["ls"])]), gamma=float(g["gamma"]), m=200)
+        reg.nystrom_centers_output = Y.T[:, idx]
+        reg.fit(X, Y)
+        return reg
+    base = fit()
+    assert base.fit_stats_["refined"] == 0
+    ctx.set_refine(1e-9, 2)
+    try:
+        ref = fit()
+        st = ref.fit_stats_
+        assert st["refined"] == 2 + 16 * 2, st
+        assert 0.0 < st["refine_ratio_inner"] < 1e-2 and 0.0 < st["refine_ratio_inner_rec"] < 1e-2, st
+        bars = 3.0 * np.maximum(env["op_roworder"], env["op_envelope"])
+        for nm, got, bar in (("A", ref.A, bars[0]), ("B", ref.B, bars[1]), ("C", ref.C, bars[2])):
+            assert relf(got, g[nm]) < bar, (nm, relf(got, g[nm]), bar)
+        assert relf(ref.A, g["A"]) <= relf(base.A, g["A"]) * 1.05
+        print("\n[refinement] A vs reference:", relf(base.A, g["A"]), "->", relf(ref.A, g["A"]), "first corrections:",
+              st["refine_ratio_inner"], st["refine_ratio_inner_rec"])
+        # pivot ratio 9.5e-5 (f2): not touched
+        g2 = golden("f2_synth_rbf_d384.npz")
+        X2, Y2 = g2["X"].astype(np.float64), g2["Y"].astype(np.float64)
+        l3 = g2["ls"] if g2["ls"].size == 3 else np.repeat(g2["ls"], 3)
+        r2 = nk.KoopmanNystromRegressor(6, kernel=nk.ThreeDimensionalKernel(*l3, Y2.shape[1]), gamma=float(g2["gamma"]), m=len(g2["idx"]))
+        r2.nystrom_centers_output = Y2.T[:, g2["idx"]]
+        r2.fit(X2, Y2)
+        assert r2.fit_stats_["refined"] == 0
+    finally:
+        ctx.set_refine(0.0, 2)
+    again = fit()
+    assert again.fit_stats_["refined"] == 0 and np.array_equal(again.A, base.A) and np.array_equal(again.C, base.C)
