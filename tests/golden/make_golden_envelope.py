@@ -21,6 +21,7 @@ the rank-recording spy of make_golden_configs.py).
     python tests/golden/make_golden_envelope.py cloth     -> f7b_cloth_cv_envelope.npz   (405 units x 4 extra sweeps)
     python tests/golden/make_golden_envelope.py duffing   -> f12b_duffing_envelope.npz   (60 fits x 3 drivers)
     python tests/golden/make_golden_envelope.py hjb       -> f8b_hjb_envelope.npz        (config 2: operators)
+    python tests/golden/make_golden_envelope.py gain      -> f6b_cloth_gain_envelope.npz (shipped LQR gain, seed 0)
 """
 import os
 import random
@@ -205,6 +206,45 @@ def hjb():
     np.savez_compressed(f"{OUT}/f8b_hjb_envelope.npz", op_envelope=env, op_roworder=row)
 
 
+def gain():
+    """The authors' shipped K_lqr_seed_0.csv (f6): how well the reference code run HERE reproduces it (gelsd, the reference as
+    it is), and how far the gain moves when its two solves use another LAPACK driver -- the bar of the build's gain.
+    benchmark_lqr_cloth.py:218-263: seed 0, m = 100, kernel l = (10, 10, 10), gamma = 1e-7, c = 0.005, Q = c C'C, R = I; the
+    DARE through scipy (control.dlqr is not installed: make_golden_configs.py)."""
+    g = np.load(f"{OUT}/f6_cloth_known_gain.npz")
+    tr, u = g["trajs"], g["inputs"]
+    X = np.ascontiguousarray(np.hstack([np.vstack((tr[i][:, :-1], u[i][:, :-1])) for i in range(30)]).T)
+    Y = np.ascontiguousarray(np.hstack([tr[i][:, 1:] for i in range(30)]).T)
+    relf = lambda a, b: float(np.linalg.norm(a - b) / np.linalg.norm(b))
+
+    def K_of(Xs, Ys):
+        np.random.seed(0)
+        reg = R.KoopmanNystromRegressor(6, kernel=R.ThreeDimensionalKernel(10, 10, 10, 192), gamma=1e-7, m=100)
+        reg.fit(Xs, Ys)
+        Q = 0.005 * reg.C.T @ reg.C
+        Q = (Q + Q.T) / 2
+        P = scipy.linalg.solve_discrete_are(reg.A, reg.B, Q, np.eye(6))
+        K = np.linalg.solve(reg.B.T @ P @ reg.B + np.eye(6), reg.B.T @ P @ reg.A)
+        return K[[0, 3, 1, 4, 2, 5], :], reg
+    K0, reg0 = K_of(X, Y)
+    out = dict(K_reference_here=K0, reproduces_shipped=relf(K0, g["K_lqr_seed_0"]))
+    print("gain: the reference run here against the shipped CSV:", out["reproduces_shipped"], flush=True)
+    env = 0.0
+    for mode in ("gelsy", "chol", "eigh"):
+        with LstsqSwap(mode):
+            Km, regm = K_of(X, Y)
+        dev = relf(Km, K0)
+        print(f"gain: {mode} moves K by {dev:.3e} (A by {relf(regm.A, reg0.A):.3e})", flush=True)
+        out[f"K_{mode}"] = dev
+        env = max(env, dev)
+    rng = np.random.default_rng(3)
+    Kp, _ = K_of(X * (1 + 1e-15 * rng.standard_normal(X.shape)), Y * (1 + 1e-15 * rng.standard_normal(Y.shape)))
+    out["K_spread"] = relf(Kp, K0)
+    out["K_envelope"] = env
+    print("gain: 1e-15 input perturbation moves K by", out["K_spread"], "; envelope", env)
+    np.savez_compressed(f"{OUT}/f6b_cloth_gain_envelope.npz", **out)
+
+
 if __name__ == "__main__":
-    for a in sys.argv[1:] or ["duffing", "cloth", "hjb"]:
-        {"cloth": cloth, "duffing": duffing, "hjb": hjb}[a]()
+    for a in sys.argv[1:] or ["duffing", "cloth", "hjb", "gain"]:
+        {"cloth": cloth, "duffing": duffing, "hjb": hjb, "gain": gain}[a]()

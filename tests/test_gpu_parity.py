@@ -414,8 +414,8 @@ def test_cloth_known_answer_gain_and_closed_loop(nk, O, golden):
     residual of 7e-5 on this system while Cholesky / LU / gelsy / plain SVD all agree with each other (residual
     5e-7) and sit 1.6e-1 away from gelsd's `sol` (tools/gelsd_accuracy_note.py).  The reference's operators
     therefore carry gelsd's own error: any accurate solver lands 3e-2 from its A and 3e-4 from its predictions
-    (the oracle's Cholesky mode shows the same numbers), so the bars here are 2e-3 on predictions, 1e-1 on the
-    gain, and tight agreement of the device closed loop with the oracle loop on the same operators."""
+    (the oracle's Cholesky mode shows the same numbers), so the bars here are 2e-3 on predictions, 3 x the reference's own driver-to-driver
+    movement on the gain (7e-2), and tight agreement of the device closed loop with the oracle loop on the same operators."""
     g = golden("f6_cloth_known_gain.npz")
     tr, u = g["trajs"], g["inputs"]
     X = np.ascontiguousarray(np.hstack([np.vstack((tr[i][:, :-1], u[i][:, :-1])) for i in range(30)]).T)
@@ -429,7 +429,13 @@ def test_cloth_known_answer_gain_and_closed_loop(nk, O, golden):
     assert relf(reg.predict(X[:200]), ref.predict(X[:200])) < 2e-3
     K = reg.solve_lqr(c=0.005)
     from nys_koop_lqr_amd.lqr import cloth_gain_for_simulator
-    assert relf(cloth_gain_for_simulator(K), g["K_lqr_seed_0"]) < 1e-1
+    # the bar of the gain comes from the reference itself (f6b, tests/golden/make_golden_envelope.py gain): run here it reproduces
+    # the shipped CSV to 2.5e-4, and with gelsy / Cholesky / eigh for its two solves its gain moves by 2.4e-2 (all three alike:
+    # gelsd is the odd one out); times 3
+    e = golden("f6b_cloth_gain_envelope.npz")
+    err_K = relf(cloth_gain_for_simulator(K), g["K_lqr_seed_0"])
+    print(f"\n[cloth known-answer gain] K vs shipped CSV {err_K:.3e}; reference with other LAPACK drivers {float(e['K_envelope']):.3e}")
+    assert err_K < 3.0 * float(e["K_envelope"])
     # closed loop in lifted space: device loop == oracle loop on the same (A,B,C,K)
     x0 = tr[0][:, :1]
     phi0, phir = reg.lift(x0), reg.lift(tr[0][:, 50:51])
