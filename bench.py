@@ -222,9 +222,9 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=min(16, os.cpu_count() or 1))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sweep", action="store_true",
-                    help="N = 1 walks the same CV-grid candidate list as the N > 1 runs (step s fits candidate s mod 15), so "
-                         "that a 1 -> N scaling curve times the same workload; the headline line (default) fits l=20, "
-                         "gamma=1e-6 every step")
+                    help="walk a 15-candidate (lengthscale, gamma) grid instead: step s on rank r fits candidate (r + N s) mod 15 (the "
+                         "units of a sharded CV sweep; their cost differs by the square-root iteration count).  Default at "
+                         "every N: each unit is the headline fit (l=20, gamma=1e-6), so a 1 -> N curve times the same work per GPU")
     ap.add_argument("--no-extras", action="store_true", help="skip the host-input and CV-sweep secondary figures")
     ap.add_argument("--concurrency", type=int, default=1,
                     help="host threads issuing independent fits concurrently on each GPU (each with its own context and "
@@ -267,7 +267,7 @@ def main():
     Z = np.ascontiguousarray(Y[idx])
     torch.cuda.synchronize()
 
-    sweep = world > 1 or args.sweep
+    sweep = args.sweep  # default at every N: each unit is the headline fit, so that the per-GPU work of the N-rank run IS the N = 1 line's
 
     def one_fit(step):
         ls, gamma = CV_GRID[(rank + world * step) % len(CV_GRID)] if sweep else (20.0, 1e-6)
@@ -343,7 +343,7 @@ def main():
                                                        "(rank + world*step) mod 15 per step"),
                        "n": n, "m": m, "d": d, "p": p, "inputs": "HBM-resident (device pointers through the C-ABI)",
                        "outputs": "A,B,C,W copied to page-locked host arrays by asynchronous DMA that overlaps the next fit; all copies complete inside the timed region",
-                       "parallelism": "1 process/GPU, independent fits per rank, RCCL all-gather of per-fit scalars",
+                       "parallelism": "1 process/GPU, independent fits per rank (the units of a sharded sweep; no data-path collective), RCCL all-gather of per-fit scalars",
                        "concurrent_fits_per_gpu": conc,
                        "timed_region": "CPython's cyclic GC disabled inside the timed region, as timeit does (a full collection "
                                        "walks ~1e6 live NumPy / SciPy / torch objects: 45-75 ms, more than one fit)"},

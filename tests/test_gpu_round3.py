@@ -213,3 +213,29 @@ def test_optional_refinement_with_doubled_precision_residuals(nk, golden):
         ctx.set_refine(0.0, 2)
     again = fit()
     assert again.fit_stats_["refined"] == 0 and np.array_equal(again.A, base.A) and np.array_equal(again.C, base.C)
+
+
+def test_blocked_solve_is_backward_stable_on_an_ill_conditioned_system(nk, golden):
+    """The O(m^3) building block alone (nk_solve_spd: blocked Cholesky, products with inverted 64 x 64 diagonal blocks + one
+    correction step each) on config 2's regularised system (cond 1.3e13, first diagonal block of the factor: cond 2e6): the
+    normwise backward error is at LAPACK's level (round 2: 1.4e-15 = 20 x LAPACK's), and the forward distance to LAPACK's
+    solution is what two backward-stable solvers differ by."""
+    import scipy.linalg
+    from oracle import nk_oracle as O
+    from nys_koop_lqr_amd import _lib
+    from nys_koop_lqr_amd.regressors import KoopmanKernelRegressor as KK
+    g = golden("f8_hjb_config2.npz")
+    X, Y, idx = g["X"], g["Y"], g["idx"]
+    n, m, p, gamma = X.shape[0], int(g["m"]), 1, float(g["gamma"])
+    k = O.KernelWrapper([float(g["ls"])]).kernel
+    Z = Y[idx]
+    Pin = np.hstack([k(X[:, :1], Z), X[:, 1:]])
+    inner = Pin.T @ Pin + gamma * n * scipy.linalg.block_diag(k(Z, Z) + 1e-6 * np.eye(m), np.eye(p))
+    rhs = (k(Y, Z).T @ Pin).T.copy()
+    Xg = KK._solve_spd(_lib.get_context(), inner, rhs)
+    Xl = scipy.linalg.cho_solve(scipy.linalg.cho_factor(inner), rhs)
+    be = lambda Xs: float(np.linalg.norm(inner @ Xs - rhs) / (np.linalg.norm(inner) * np.linalg.norm(Xs)))
+    print(f"\n[blocked solve, cond {np.linalg.cond(inner):.1e}] backward error GPU {be(Xg):.2e} LAPACK {be(Xl):.2e}; "
+          f"GPU vs LAPACK {relf(Xg, Xl):.2e}")
+    assert be(Xg) < 2.0 * be(Xl) and be(Xg) < 2e-16
+    assert relf(Xg, Xl) < 5e-3   # cond x eps = 3e-3: the forward error either of them may carry
