@@ -285,6 +285,15 @@ inline int chol_fix_enabled() {
 }
 // trailing update C -= P P^T (K = 64) of up to two systems (nk_trail.hip); false: not that shape, use launch_gemm_pair
 bool launch_chol_trail_pair(nk_ctx* ctx, const GemmCall* calls, int ncalls, int* rc);
+// ... fused with the diagonal-block factorisation of the NEXT block step `blk` (nb[q]: its order, 0 = system q has none; the
+// block is calls[q].C): one launch instead of two, the diagonal kernel off the critical path.  false: not that shape, nothing
+// launched (the caller issues the two launches separately)
+bool launch_chol_trail_potrf_pair(nk_ctx* ctx, const GemmCall* calls, int ncalls, const int* nb, double* const* Linv, int blk,
+                                  double* const* plog, int* rc);
+inline bool chol_fuse_enabled() {  // NYSKOOP_CHOL_FUSE=0 (read per call): separate launches, for A/B runs and the bit-identity test
+  const char* e = getenv("NYSKOOP_CHOL_FUSE");
+  return !(e && e[0] == '0');
+}
 // panel product P <- P Linv_jj^T (64 x 64) of up to two systems (nk_trail.hip); false: not that shape
 bool launch_chol_panel_pair(nk_ctx* ctx, const GemmCall* calls, int ncalls, int* rc);
 // E_q <- E_q L_q^-1 on the extra rows of up to two factored systems, one launch (nk_trsm.hip)

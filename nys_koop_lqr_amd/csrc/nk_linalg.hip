@@ -588,12 +588,27 @@ static int reset_pivots(nk_ctx* ctx) {
   return NK_OK;
 }
 
+// order, workspace and pivot log of diagonal block jb + 1 of every system (order 0: the system has no such block)
+static void next_block(const CholSys* sys, int nsys, int jb, int* nbn, double** Lin, double** Pln) {
+  constexpr int NB = CHOL_NB;
+  const int j1 = (jb + 1) * NB;
+  for (int q = 0; q < nsys; ++q) {
+    const CholSys& y = sys[q];
+    if (j1 >= y.m) continue;
+    nbn[q] = y.m - j1 < NB ? y.m - j1 : NB;
+    Lin[q] = y.Linv + (size_t)(jb + 1) * CHOL_WS;
+    Pln[q] = y.pivlog ? y.pivlog + j1 : nullptr;
+  }
+}
+
 int cholesky_lower_pair_async(nk_ctx* ctx, const CholSys* sys, int nsys) {
   constexpr int NB = CHOL_NB;
   NK_REQUIRE(nsys >= 1 && nsys <= 2, "cholesky_lower_pair: 1..2 systems");
   NK_TRY(reset_pivots(ctx));
   int nblk = 0;
   for (int q = 0; q < nsys; ++q) nblk = std::max(nblk, (sys[q].m + NB - 1) / NB);
+  const bool fuse = chol_fuse_enabled();
+  bool diag_done = false;  // the diagonal block of this step was factored by the previous step's fused launch
   for (int jb = 0; jb < nblk; ++jb) {
     const int j0 = jb * NB;
     double* Ajj[2] = {nullptr, nullptr};
@@ -624,11 +639,25 @@ int cholesky_lower_pair_async(nk_ctx* ctx, const CholSys* sys, int nsys) {
         trail[q].opts.tri = TRI_LOWER;
       }
     }
-    NK_TRY(launch_potrf_diag_pair(ctx, Ajj, lda, nbj, Li, nsys, jb, Pl));
+    if (!diag_done) NK_TRY(launch_potrf_diag_pair(ctx, Ajj, lda, nbj, Li, nsys, jb, Pl));
+    diag_done = false;
     {
       int rc_panel = NK_OK;  // 64 x 64 panel product: specialised kernel (nk_trail.hip), generic engine otherwise
       if (!launch_chol_panel_pair(ctx, panel, nsys, &rc_panel)) NK_TRY(launch_gemm_pair(ctx, false, true, panel, nsys));
       NK_TRY(rc_panel);
+    }
+    // trailing update -- in one launch with the factorisation of the next diagonal block where the shapes allow
+    if (fuse && jb + 1 < nblk) {
+      int rc_f = NK_OK;
+      int nbn[2] = {0, 0};
+      double* Lin[2] = {nullptr, nullptr};
+      double* Pln[2] = {nullptr, nullptr};
+      next_block(sys, nsys, jb, nbn, Lin, Pln);
+      if (launch_chol_trail_potrf_pair(ctx, trail, nsys, nbn, Lin, jb + 1, Pln, &rc_f)) {
+        NK_TRY(rc_f);
+        diag_done = true;
+        continue;
+      }
     }
     {
       int rc_trail = NK_OK;  // K = 64 rank update: specialised kernel (nk_trail.hip), generic engine otherwise
@@ -738,6 +767,8 @@ int cholesky_aug_pair_async(nk_ctx* ctx, const CholSys* sys, int nsys, hipEvent_
     NK_HIP(hipEventRecord(ev[1], s_chain));
     NK_HIP(hipStreamWaitEvent(s_rest, ev[1], 0));
   }
+  const bool fuse = chol_fuse_enabled();
+  bool diag_done = false;  // the diagonal block of this step was factored by the previous step's fused launch
   for (int jb = 0; jb < nblk; ++jb) {
     if (pause != nullptr && jb == pause_step) NK_HIP(hipStreamWaitEvent(ctx->stream, pause, 0));
     const int j0 = jb * NB;
@@ -782,11 +813,25 @@ int cholesky_aug_pair_async(nk_ctx* ctx, const CholSys* sys, int nsys, hipEvent_
         }
       }
     }
-    NK_TRY(launch_potrf_diag_pair(ctx, Ajj, lda, nbj, Li, nsys, jb, Pl));
+    if (!diag_done) NK_TRY(launch_potrf_diag_pair(ctx, Ajj, lda, nbj, Li, nsys, jb, Pl));
+    diag_done = false;
     {
       int rc_panel = NK_OK;  // 64 x 64 panel product: specialised kernel (nk_trail.hip), generic engine otherwise
       if (!launch_chol_panel_pair(ctx, panel, nsys, &rc_panel)) NK_TRY(launch_gemm_pair(ctx, false, true, panel, nsys));
       NK_TRY(rc_panel);
+    }
+    // trailing update -- in one launch with the factorisation of the next diagonal block where the shapes allow
+    if (fuse && !lookahead && jb + 1 < nblk) {
+      int rc_f = NK_OK;
+      int nbn[2] = {0, 0};
+      double* Lin[2] = {nullptr, nullptr};
+      double* Pln[2] = {nullptr, nullptr};
+      next_block(sys, nsys, jb, nbn, Lin, Pln);
+      if (launch_chol_trail_potrf_pair(ctx, trail, nsys, nbn, Lin, jb + 1, Pln, &rc_f)) {
+        NK_TRY(rc_f);
+        diag_done = true;
+        continue;
+      }
     }
     auto update = [&](const GemmCall* calls) -> int {  // K = 64 rank update: specialised kernel, generic engine otherwise
       int rc_trail = NK_OK;

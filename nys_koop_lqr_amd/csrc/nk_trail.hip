@@ -8,10 +8,10 @@
 // lane groups, any assignment works as long as both operands use the same one), multiplies on the matrix pipe
 // (4 waves x 4 x 4 tiles of v_mfma_f64_16x16x4) and read-modify-writes the 128 x 128 tile of C.  No LDS, no barriers.
 #include "nk_common.h"
+#include "nk_potrf_body.h"
 
 namespace nk {
 
-typedef double d4 __attribute__((ext_vector_type(4)));
 
 struct TrailSys {
   const double* P;  // panel: rows x 64
@@ -101,10 +101,33 @@ static nk::TwinReg chol_trail_kernel_twin_reg(reinterpret_cast<const void*>(stat
 
 // trailing updates of up to two systems; calls[q] as prepared for the generic engine (A = B = panel, K = 64, alpha = -1,
 // beta = 1, TRI_LOWER).  Returns false when a call does not have that shape (the caller then uses the generic engine).
-bool launch_chol_trail_pair(nk_ctx* ctx, const GemmCall* calls, int ncalls, int* rc) {
-  *rc = NK_OK;
-  TrailBatch tb;
-  int maxblocks = 0;
+bool launch_chol_trail_pair(nk_ctx* ctx, const GemmCall* calls, int ncalls, int* rc);
+
+// ---------------------------------------------------------------------------------------------------------------
+// Trailing update of step j AND the diagonal-block factorisation of step j + 1 in one launch.  The next diagonal block is the
+// 64 x 64 sub-tile of wave 0 of workgroup 0: as soon as that wave has written it back, it factors and inverts it
+// (potrf_diag_kernel_body, one wave) while the other workgroups are still on their tiles -- the ~30 us of the diagonal
+// kernel leave the critical path wherever the trailing update takes as long, and every block step loses one of its three
+// kernel boundaries.  Same arithmetic in the same order as the two separate launches: bit-identical results
+// (NYSKOOP_CHOL_FUSE=0 issues them separately).
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void chol_trail_potrf_kernel_body(const TrailBatch& tb, const PotrfBatch& pb, int blk) {
+  chol_trail_kernel_body(tb);
+  if (blockIdx.x == 0 && __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 0 && pb.nb[blockIdx.y] > 0) {
+    __threadfence();  // this wave's own stores of the block are visible to its loads (another lane layout) below
+    potrf_diag_kernel_body(pb, blk, blockIdx.y, threadIdx.x & 63);
+  }
+}
+__global__ void __launch_bounds__(256) chol_trail_potrf_kernel(TrailBatch tb, PotrfBatch pb, int blk) { chol_trail_potrf_kernel_body(tb, pb, blk); }
+__global__ void __launch_bounds__(256) chol_trail_potrf_kernel_batched(const nk::ArgPack<TrailBatch, PotrfBatch, int>* table) {
+  chol_trail_potrf_kernel_body(table[blockIdx.z].v, table[blockIdx.z].rest.v, table[blockIdx.z].rest.rest.v);
+}
+static nk::TwinReg chol_trail_potrf_twin_reg(reinterpret_cast<const void*>(static_cast<void (*)(TrailBatch, PotrfBatch, int)>(chol_trail_potrf_kernel)),
+                                             reinterpret_cast<const void*>(chol_trail_potrf_kernel_batched),
+                                             sizeof(nk::ArgPack<TrailBatch, PotrfBatch, int>), "chol_trail_potrf_kernel");
+
+static bool fill_trail_batch(const GemmCall* calls, int ncalls, TrailBatch& tb, int& maxblocks) {
+  maxblocks = 0;
   for (int q = 0; q < 2; ++q) {
     TrailSys& t = tb.s[q];
     t = TrailSys{};
@@ -119,10 +142,47 @@ bool launch_chol_trail_pair(nk_ctx* ctx, const GemmCall* calls, int ncalls, int*
     t.nblocks = t.tiles_n * (t.tiles_n + 1) / 2 + (tiles_m - t.tiles_n) * t.tiles_n;
     if (t.nblocks > maxblocks) maxblocks = t.nblocks;
   }
+  return true;
+}
+
+bool launch_chol_trail_pair(nk_ctx* ctx, const GemmCall* calls, int ncalls, int* rc) {
+  *rc = NK_OK;
+  TrailBatch tb;
+  int maxblocks = 0;
+  if (!fill_trail_batch(calls, ncalls, tb, maxblocks)) return false;
   if (maxblocks == 0) return true;
   hipLaunchKernelGGL(chol_trail_kernel, dim3((unsigned)maxblocks, 2), dim3(256), 0, ctx->stream, tb);
   if (hipGetLastError() != hipSuccess) {
     set_error("chol_trail launch failed");
+    *rc = NK_ERR_HIP;
+  }
+  return true;
+}
+
+// trailing updates of step `blk - 1` (calls[q] as for launch_chol_trail_pair) fused with the diagonal-block factorisation of
+// step `blk` of the same systems (nb[q] = order of that block, 0: the system has none; its block is calls[q].C).  false: not
+// that shape, nothing launched.
+bool launch_chol_trail_potrf_pair(nk_ctx* ctx, const GemmCall* calls, int ncalls, const int* nb, double* const* Linv, int blk,
+                                  double* const* plog, int* rc) {
+  *rc = NK_OK;
+  TrailBatch tb;
+  int maxblocks = 0;
+  if (!fill_trail_batch(calls, ncalls, tb, maxblocks) || maxblocks == 0) return false;
+  PotrfBatch pb;
+  for (int q = 0; q < 2; ++q) {
+    const bool on = q < ncalls && nb[q] > 0 && tb.s[q].nblocks > 0;
+    if (q < ncalls && nb[q] > 0 && tb.s[q].nblocks == 0) return false;  // a diagonal block without a trailing update before it
+    pb.A[q] = on ? tb.s[q].C : nullptr;
+    pb.lda[q] = on ? tb.s[q].ldc : 0;
+    pb.nb[q] = on ? nb[q] : 0;
+    pb.Linv[q] = on ? Linv[q] : nullptr;
+    pb.info[q] = ctx->d_info + info_base(ctx) + q;
+    pb.piv[q] = ctx->d_piv + 2 * (info_base(ctx) + q);
+    pb.plog[q] = (on && plog) ? plog[q] : nullptr;
+  }
+  hipLaunchKernelGGL(chol_trail_potrf_kernel, dim3((unsigned)maxblocks, 2), dim3(256), 0, ctx->stream, tb, pb, blk);
+  if (hipGetLastError() != hipSuccess) {
+    set_error("chol_trail_potrf launch failed");
     *rc = NK_ERR_HIP;
   }
   return true;

@@ -239,3 +239,35 @@ def test_blocked_solve_is_backward_stable_on_an_ill_conditioned_system(nk, golde
           f"GPU vs LAPACK {relf(Xg, Xl):.2e}")
     assert be(Xg) < 2.0 * be(Xl) and be(Xg) < 2e-16
     assert relf(Xg, Xl) < 5e-3   # cond x eps = 3e-3: the forward error either of them may carry
+
+
+def test_fused_trailing_update_and_next_diagonal_block_give_the_same_bits(nk, golden, monkeypatch):
+    """chol_trail_potrf_kernel (the trailing update of a block step and the factorisation of the next diagonal block in one
+    launch, by the wave that owns that block) performs the arithmetic of the two separate launches: fits and the stand-alone
+    solve compute the same bits with NYSKOOP_CHOL_FUSE=0 (read per call).  Shapes: several blocks with a short last one and
+    an odd number of right-hand-side rows (m = 700, p = 3), a single block (f4: m = 40), and the CV sweep's lock-step form."""
+    from nys_koop_lqr_amd import harness
+    rng = np.random.default_rng(8)
+    n, d, p, m = 3000, 40, 3, 700
+    S = rng.standard_normal((n, d)); U = rng.standard_normal((n, p))
+    Y = np.tanh(S @ (rng.standard_normal((d, d)) * 0.9 / np.sqrt(d))) + U @ (rng.standard_normal((p, d)) * 0.1)
+    X = np.hstack([S, U])
+    g4 = golden("f4_hjb_matern.npz")
+
+    def run():
+        reg = nk.KoopmanNystromRegressor(p, kernel=nk.ThreeDimensionalKernel(6., 6., 6., d), gamma=1e-5, m=m)
+        reg.nystrom_centers_output = np.ascontiguousarray(Y[:m].T)
+        reg.fit(X, Y)
+        r4 = nk.KoopmanNystromRegressor(1, kernel=nk.KernelWrapper(g4["ls"]), gamma=float(g4["gamma"]), m=len(g4["idx"]))
+        r4.nystrom_centers_output = g4["Y"].astype(np.float64).T[:, g4["idx"]]
+        r4.fit(g4["X"].astype(np.float64), g4["Y"].astype(np.float64))
+        cands = [dict(kernel=nk.ThreeDimensionalKernel(l, l, l, d), gamma=1e-5, m=200) for l in (4.0, 8.0)]
+        np.random.seed(3)
+        cv = harness.grid_search_cv(X[:1000], Y[:1000], p, cands, n_splits=5, batch=5, batch_groups=2)
+        return [np.array(a) for a in (reg.A, reg.B, reg.C, r4.A, r4.C, cv["split_scores"])]
+    fused = run()
+    monkeypatch.setenv("NYSKOOP_CHOL_FUSE", "0")
+    apart = run()
+    monkeypatch.delenv("NYSKOOP_CHOL_FUSE")
+    for a, b in zip(fused, apart):
+        assert np.array_equal(a, b)
