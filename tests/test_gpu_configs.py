@@ -106,6 +106,37 @@ def test_cloth_cv_grid_full_shape_vs_reference_gridsearch(nk, golden):
 
 
 # ---------------------------------------------------------------------------------------------------------------
+# configs 1 and 2: the hyper-parameter searches (learn_hyperparams of benchmark_lqr_classic.py:44-64, benchmark_lqr_hjb.py:47-70)
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name,units", [("f13_duffing_cv.npz", 80), ("f14_hjb_cv.npz", 240)])
+def test_duffing_and_hjb_hyperparameter_searches_vs_reference_gridsearch(nk, golden, name, units):
+    """The (kernel, gamma) x 5-fold searches of configs 1 and 2 at their real shape (n = 3980 validation rows, m = 500, 16 gammas;
+    1 / 3 Matern kernels) against scikit-learn's GridSearchCV driving the reference estimator (f13 / f14,
+    tests/golden/make_golden_cv.py): every (candidate, fold) score within max(10 x the reference's own movement under a 1e-15
+    input perturbation, 3 x its movement with another LAPACK driver, 1e-7), the same best candidate; lock-step batched."""
+    from nys_koop_lqr_amd import harness
+    g = golden(name)
+    X, Y = g["X"], g["Y"]
+    assert X.shape[0] == 3980 and g["split_scores"].size == units  # 20 x int(2 // 0.01) = 20 x 199 rows, as the reference draws them
+    cands = [dict(kernel=nk.KernelWrapper(g["ls_grid"][int(k)]), gamma=float(gm), m=int(g["m"]))
+             for k, gm in zip(g["order_kernel"], g["order_gamma"])]
+    np.random.seed(int(g["seed"]))
+    t0 = time.perf_counter()
+    res = harness.grid_search_cv(X, Y, 1, cands, n_splits=5, batch=16, batch_groups=2)
+    dt = time.perf_counter() - t0
+    sc, ref = res["split_scores"], g["split_scores"]
+    assert sc.shape == ref.shape and np.all(np.isfinite(sc))
+    rel = np.abs(sc - ref) / np.abs(ref)
+    bar = np.maximum(np.maximum(10.0 * g["spread"], 3.0 * g["envelope"]), 1e-7)
+    worst = np.unravel_index(np.argmax(rel / bar), rel.shape)
+    print(f"\n[{name}] {units} units in {dt:.2f} s = {units / dt:.0f} units/s; score error max {rel.max():.2e} median "
+          f"{np.median(rel):.2e}; worst unit {worst}: err {rel[worst]:.2e} = {float((rel / bar)[worst]):.2f} of its bar (spread "
+          f"{g['spread'][worst]:.2e}, envelope {g['envelope'][worst]:.2e})")
+    assert (rel / bar).max() <= 1.0, (worst, float(rel[worst]), float(bar[worst]))
+    assert res["best_index"] == int(np.argmax(g["mean_test_score"]))
+
+
+# ---------------------------------------------------------------------------------------------------------------
 # config 2: HJB, N = 1e4, m = 200, Nystrom vs exact kernel
 # ---------------------------------------------------------------------------------------------------------------
 def test_hjb_config2_nystrom_vs_exact_kernel(nk, O, golden):
