@@ -907,22 +907,44 @@ static int fit_impl(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int6
 
   // ---- landmark kernels (regressors.py:139,143,144) -----------------------------------------------------------------
   double *Kmm = nullptr, *Kj = nullptr, *Kj_in = nullptr, *Kxo = nullptr;
+  bool landmarks_aside = false;
   if (mode != FIT_GRAM) {
   NK_TRY(arena_alloc_t(ctx, (size_t)m * m, &Kmm));
   NK_TRY(arena_alloc_t(ctx, (size_t)m * m, &Kj));
-  NK_TRY(launch_kmat(ctx, kd->type, zo.ptr, zo.ld, m, zo.ptr, zo.ld, m, d, mdl->winv, kd->sigma0, Kmm, m));
-  NK_TRY(launch_copy2d(ctx, Kmm, m, Kj, m, m, m));
-  NK_TRY(launch_add_diag(ctx, Kj, m, m, jitter));
-  NK_HIP(hipEventRecord(ev[8], ctx->stream));  // K_mm + jitter is ready (preparation stream: sqrtm_prepare)
   if (same_centers) {
     Kj_in = Kj;
     Kxo = Kmm;
   } else {
     NK_TRY(arena_alloc_t(ctx, (size_t)m * m, &Kj_in));
     NK_TRY(arena_alloc_t(ctx, (size_t)m * m, &Kxo));
-    NK_TRY(launch_kmat(ctx, kd->type, zi.ptr, zi.ld, m, zi.ptr, zi.ld, m, d, mdl->winv, kd->sigma0, Kj_in, m));
-    NK_TRY(launch_add_diag(ctx, Kj_in, m, m, jitter));
-    NK_TRY(launch_kmat(ctx, kd->type, zi.ptr, zi.ld, m, zo.ptr, zo.ld, m, d, mdl->winv, kd->sigma0, Kxo, m));
+  }
+  // Nothing needs the landmark matrices before the fused Gram launch has ended (the square root's preparation chain, the
+  // regularisers of the two systems), and at the headline shape K_mm is 160 us on 16 workgroups: for large fits they are
+  // built on the preparation stream, beside the row preparation and the kernel blocks instead of in front of them
+  // (ev[8]: ready; the main stream waits for it where it assembles the systems).
+  {
+    const char* la = getenv("NYSKOOP_LANDMARKS_ASIDE");  // 0: on the main stream, in front of the kernel blocks (read per fit: A/B runs)
+    landmarks_aside = mode == FIT_FULL && n_eff >= 20000 && m >= 1024 && !ctx_recording(ctx) && !(la && la[0] == '0');
+  }
+  {
+    hipStream_t s0 = ctx->stream;
+    if (landmarks_aside) {
+      NK_HIP(hipEventRecord(ev[12], ctx->stream));  // the staged landmarks / lengthscales are ready
+      ctx->stream = ctx->stream_prep;
+      NK_HIP(hipStreamWaitEvent(ctx->stream, ev[12], 0));
+    }
+    int rc_l = launch_kmat(ctx, kd->type, zo.ptr, zo.ld, m, zo.ptr, zo.ld, m, d, mdl->winv, kd->sigma0, Kmm, m);
+    if (rc_l == NK_OK) rc_l = launch_copy2d(ctx, Kmm, m, Kj, m, m, m);
+    if (rc_l == NK_OK) rc_l = launch_add_diag(ctx, Kj, m, m, jitter);
+    if (rc_l == NK_OK && !same_centers) {
+      rc_l = launch_kmat(ctx, kd->type, zi.ptr, zi.ld, m, zi.ptr, zi.ld, m, d, mdl->winv, kd->sigma0, Kj_in, m);
+      if (rc_l == NK_OK) rc_l = launch_add_diag(ctx, Kj_in, m, m, jitter);
+      if (rc_l == NK_OK) rc_l = launch_kmat(ctx, kd->type, zi.ptr, zi.ld, m, zo.ptr, zo.ld, m, d, mdl->winv, kd->sigma0, Kxo, m);
+    }
+    const hipError_t he = rc_l == NK_OK ? hipEventRecord(ev[8], ctx->stream) : hipSuccess;  // the landmark matrices are ready
+    ctx->stream = s0;
+    NK_TRY(rc_l);
+    NK_HIP(he);
   }
   }
   // Gram accumulators (regressors.py:151,153,162,164), one packed block (see gram_doubles):
@@ -1275,6 +1297,7 @@ static int fit_impl(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int6
   //        [A B] = S^-1 (cross inner^-1) blkdiag(K_xo S^-1, I)            cross = G2     (regressors.py:152-156)
   //        C     = (left_rec inner_rec^-1) S                               left_rec = G4  (regressors.py:163-166)
   //      so the right-hand sides are cross^T (m columns) and left_rec^T (only d columns instead of the reference's m).
+  if (landmarks_aside) NK_HIP(hipStreamWaitEvent(ctx->stream, ev[8], 0));  // (long done: built beside the kernel blocks)
   NK_TRY(launch_axpby2d(ctx, gamma_n, Kj_in, m, 1.0, G1, mp, m, m));               // inner = G1 + gamma_n*blkdiag(K, I)
   if (p > 0) NK_TRY(launch_add_diag(ctx, G1 + (int64_t)m * mp + m, mp, p, gamma_n));
   NK_TRY(launch_axpby2d(ctx, gamma_n, Kj, m, 1.0, G3, m, m, m));                   // inner_rec = gamma_n K + G3
