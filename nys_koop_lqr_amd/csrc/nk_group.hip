@@ -394,9 +394,41 @@ int x_align() {
   return c ? group_align(c) : NK_OK;
 }
 
+// Copies a recorded sequence can MERGE: a plain hipMemcpyAsync is one stream operation per member (45 000 of them in six
+// sweeps of the 405-unit grid, 13 % of the sweep's GPU time at ~5 us each, none of them shared), a copy KERNEL has a batched
+// twin like every other kernel.  Device-to-device copies and the small device-to-host copies into the context's own pinned
+// mirrors (h_scalars / h_info: host memory the device can store to) are therefore recorded as launches of this kernel.
+__device__ __forceinline__ void copy_words_kernel_body(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, int64_t n) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+__global__ void __launch_bounds__(256) copy_words_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, int64_t n) { copy_words_kernel_body(src, dst, n); }
+NK_BATCHED_TWIN(copy_words_kernel, (256), const uint32_t*, uint32_t*, int64_t)
+
+static bool ctx_pinned_mirror(const nk_ctx* c, const void* p, size_t bytes) {
+  const char* q = static_cast<const char*>(p);
+  const char* hs = reinterpret_cast<const char*>(c->h_scalars);
+  const char* hi = reinterpret_cast<const char*>(c->h_info);
+  return (hs && q >= hs && q + bytes <= hs + 64 * sizeof(double)) || (hi && q >= hi && q + bytes <= hi + 64 * sizeof(int));
+}
+
 hipError_t x_memcpy_async(void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t s) {
   nk_ctx* c = rec_ctx();
   if (!c) return hipMemcpyAsync(dst, src, bytes, kind, s);
+  static const bool as_kernels = !(getenv("NYSKOOP_GROUP_COPY_KERNELS") && getenv("NYSKOOP_GROUP_COPY_KERNELS")[0] == '0');
+  const bool words = bytes > 0 && bytes % 4 == 0 && reinterpret_cast<uintptr_t>(dst) % 4 == 0 && reinterpret_cast<uintptr_t>(src) % 4 == 0;
+  if (as_kernels && words &&
+      (kind == hipMemcpyDeviceToDevice || (kind == hipMemcpyDeviceToHost && bytes <= 512 && ctx_pinned_mirror(c, dst, bytes)))) {
+    const int64_t n = (int64_t)(bytes / 4);
+    const int64_t blocks = (n + 1023) / 1024;  // four words per thread
+    ArgPack<const uint32_t*, uint32_t*, int64_t> pk;
+    memset(static_cast<void*>(&pk), 0, sizeof(pk));
+    pack_fill(pk, static_cast<const uint32_t*>(src), static_cast<uint32_t*>(dst), n);
+    std::vector<uint32_t> offs;
+    pack_offsets(pk, reinterpret_cast<const char*>(&pk), offs);
+    (void)group_record_kernel(c, reinterpret_cast<const void*>(copy_words_kernel), dim3((unsigned)(blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks))),
+                              dim3(256), 0, &pk, sizeof(pk), offs);
+    return hipSuccess;
+  }
   GroupOp op;
   op.kind = OP_MEMCPY; op.dst = dst; op.src = src; op.bytes = bytes; op.mk = kind;
   st(c)->ops.push_back(op);
