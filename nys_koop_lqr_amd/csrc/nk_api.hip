@@ -414,8 +414,9 @@ int nk_create(int device, nk_ctx** out) {
   NK_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->d_info), 256));
   ctx->d_piv = reinterpret_cast<unsigned long long*>(ctx->d_info + 16);  // 8 x 8 bytes behind the 4 flag slots
   NK_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->d_scalars), 64 * sizeof(double)));
-  NK_HIP(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_scalars), 64 * sizeof(double)));
-  NK_HIP(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_info), 256));
+  // (mapped + coherent, explicitly: in lock-step groups the device stores to these mirrors directly, nk_group.hip)
+  NK_HIP(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_scalars), 64 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
+  NK_HIP(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_info), 256, hipHostMallocMapped | hipHostMallocCoherent));
   ctx->h_piv = reinterpret_cast<unsigned long long*>(ctx->h_info + 16);
   for (int i = 0; i < 16; ++i) NK_HIP(hipEventCreate(&ctx->ev[i]));
   NK_HIP(hipEventCreateWithFlags(&ctx->ev_ext, hipEventDisableTiming));
