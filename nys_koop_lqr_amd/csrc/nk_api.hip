@@ -1056,6 +1056,7 @@ static int fit_impl(nk_ctx* ctx, const nk_kernel_desc* kd, const double* X, int6
     const double budget = (b ? atof(b) : 48.0) * 1073741824.0;
     pass_rows = (int64_t)(budget / ((double)ldf * felem));
     if (pass_rows < 1024) pass_rows = 1024;
+    pass_rows &= ~(int64_t)1023;  // whole k-steps per pass (the assembly k loops take K ranges of full steps only)
     if (host_passes > 1) {  // pipelined upload: at least `host_passes` passes (more if the workspace budget says so)
       const int64_t per = ((n_eff + host_passes - 1) / host_passes + 1023) & ~(int64_t)1023;
       if (per < pass_rows) pass_rows = per;

@@ -13,6 +13,7 @@
 // ahead of the MFMAs that use them, one barrier per step.
 #include "nk_common.h"
 #include "nk_tn_shared.h"
+#include "nk_tnf_kstep.inc"
 
 #include <cstdlib>
 
@@ -252,6 +253,100 @@ template <int EPI>
 __global__ void __launch_bounds__(256, 2) gemm_tn_f32_kernel(TnParamsF P) {
   tnf_body<EPI>(P);
 }
+// ---------------------------------------------------------------------------------------------------------------
+// The Gram launches with the WHOLE k loop as one hand-scheduled assembly block (nk_tnf_kstep.inc, tools/gen_tnf_kstep.py):
+// fp32 accumulators double buffered in the accumulation registers, the flush into the fp64 shadows (every k-step) in the
+// gaps between the matrix instructions.  One workgroup per CU (128 accumulation + ~150 vector registers).  Same products,
+// same flush order as tnf_body<0> with flush_steps = 1: bit-identical partial tiles.  Requirements (checked by the
+// launcher): K a multiple of 32, so that every K range consists of full steps.
+// ---------------------------------------------------------------------------------------------------------------
+typedef double d16v __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ void tnf_gram_asm_body(const TnParamsF& P) {
+  extern __shared__ __attribute__((aligned(16))) float fsmem[];
+  const int split = blockIdx.x % P.splitk;
+  const int gt = blockIdx.x / P.splitk;
+  int pi = 0;
+#pragma unroll
+  for (int q = 1; q < TN_MAXP; ++q)
+    if (q < P.nprob && gt >= P.p[q].tile_begin) pi = q;
+  const TnDevF pr = P.p[pi];
+  int tm, tn;
+  tn_tile_coords(gt - pr.tile_begin, pr.tri, pr.tiles_n, pr.M, tm, tn);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int half = lane >> 5, l32 = lane & 31;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int kbeg = split * P.klen;
+  const int kend = min(P.K, kbeg + P.klen);
+  const int nfull = kend > kbeg ? (kend - kbeg) / FBK : 0;
+  const int ca = min(tm * TBM + l32 * 4, (pr.M - 1) & ~3);
+  const int cb = min(tn * TBM + l32 * 4, (pr.N - 1) & ~3);
+  const uint32_t lds0 = (uint32_t)(uintptr_t)fsmem;
+  d16v s00, s01, s10, s11;
+#pragma unroll
+  for (int v = 0; v < 16; ++v) { s00[v] = 0.0; s01[v] = 0.0; s10[v] = 0.0; s11[v] = 0.0; }
+  if (nfull > 0) {
+    // first stage: row pairs wave, wave + 4, ... of both panels (per-lane addresses; the block uses scalar row pointers)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int rp = wave + 4 * q;
+      const int k = kbeg + 2 * rp + half;
+      dma2_rows(pr.A + (int64_t)k * pr.lda + ca, lds0 + (uint32_t)(2 * rp * FROW) * 4u);
+      dma2_rows(pr.B + (int64_t)k * pr.ldb + cb, lds0 + (uint32_t)(FPANEL + 2 * rp * FROW) * 4u);
+    }
+    dma_wait_all_f();
+    __syncthreads();
+    const uint32_t ard = lds0 + (uint32_t)(half * FROW + l32 + wm * 64) * 4u;
+    const uint32_t brd = lds0 + (uint32_t)(FPANEL + half * FROW + l32 + wn * 64) * 4u;
+    const uint32_t voa = (uint32_t)(half * pr.lda + ca) * 4u;  // this lane's row of a pair, its four columns
+    const uint32_t vob = (uint32_t)(half * pr.ldb + cb) * 4u;
+    const uint32_t stra = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(pr.lda * 32));  // 8 rows, in bytes
+    const uint32_t strb = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(pr.ldb * 32));
+    const uint32_t dst0 = (uint32_t)__builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(wave * 2 * FROW) * 4u);
+    const int steady = nfull - 1;
+    uint32_t cnt = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(steady / 2));
+    const uint32_t flags = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(steady & 1));
+    const uint64_t ra = (uint64_t)(uintptr_t)(pr.A + (int64_t)(kbeg + FBK + 2 * wave) * pr.lda);
+    const uint64_t rb = (uint64_t)(uintptr_t)(pr.B + (int64_t)(kbeg + FBK + 2 * wave) * pr.ldb);
+    const uint64_t rowa = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(ra >> 32)) << 32) |
+                          (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)ra);
+    const uint64_t rowb = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(rb >> 32)) << 32) |
+                          (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)rb);
+    asm volatile(NK_TNF_KLOOP_ASM
+                 : "+{v[128:159]}"(s00), "+{v[160:191]}"(s01), "+{v[192:223]}"(s10), "+{v[224:255]}"(s11), [cnt] "+s"(cnt)
+                 : [ard] "v"(ard), [brd] "v"(brd), [voa] "v"(voa), [vob] "v"(vob), [rowa] "s"(rowa), [rowb] "s"(rowb),
+                   [stra] "s"(stra), [strb] "s"(strb), [dst0] "s"(dst0), [flags] "s"(flags)
+                 : NK_TNF_CLOBBERS);
+  }
+  // element (block i, j; register v) of a wave's 64 x 64 sub-tile: row = i*32 + 8*(v/4) + 4*half + v%4, col = j*32 + l32
+  const bool direct = P.splitk == 1;
+  const bool mirror = direct && pr.tri == TRI_UPPER_MIRROR && tm != tn;
+  double* out = direct ? nullptr : P.slab + ((int64_t)gt * P.splitk + split) * (TBM * TBM);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const int r = wm * 64 + i * 32 + 8 * (v >> 2) + 4 * half + (v & 3);
+        const int c = wn * 64 + j * 32 + l32;
+        const double val = i == 0 ? (j == 0 ? s00[v] : s01[v]) : (j == 0 ? s10[v] : s11[v]);
+        if (!direct) {
+          out[r * TBM + c] = val;
+        } else {
+          const int row = tm * TBM + r, col = tn * TBM + c;
+          if (row < pr.M && col < pr.N) {
+            double w = val;
+            if (pr.beta != 0.0) w += pr.beta * pr.C[(int64_t)row * pr.ldc + col];
+            pr.C[(int64_t)row * pr.ldc + col] = w;
+            if (mirror) pr.C[(int64_t)col * pr.ldc + row] = w;
+          }
+        }
+      }
+}
+__global__ void __launch_bounds__(256, 2) gram_fused_f32_asm_kernel(TnParamsF P) { tnf_gram_asm_body(P); }
+
 // the fit's fused Gram launch in fp32, under its own name for the profiler
 __global__ void __launch_bounds__(256, 2) gram_fused_f32_kernel(TnParamsF P) { tnf_body<0>(P); }
 
@@ -269,6 +364,7 @@ static int tnf_attrs() {
   NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_f32_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, F32_LDS_BYTES));
   NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_f32_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, F32_LDS_BYTES));
   NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gram_fused_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, F32_LDS_BYTES));
+  NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gram_fused_f32_asm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, F32_LDS_BYTES));
   done = true;
   return NK_OK;
 }
@@ -302,6 +398,10 @@ int launch_gemm_tn_f32_multi(nk_ctx* ctx, const TnProblemF* probs, int nprob, in
     R.p[q] = R.p[0]; R.p[q].tile_begin = 1 << 30;
   }
   const int ktiles_total = (int)((K + FBK - 1) / FBK);
+  // the assembly k loop (one workgroup per CU): every K range must consist of full steps, the flush interval must be 1
+  const int flush_req = getenv("NYSKOOP_F32_FLUSH") ? atoi(getenv("NYSKOOP_F32_FLUSH")) : 1;
+  const char* fa = getenv("NYSKOOP_F32_ASM");  // read per launch: 0 = the compiler-scheduled kernel (A/B runs, bit-identity test)
+  const bool use_asm = !(fa && fa[0] == '0') && K % FBK == 0 && K >= FBK && flush_req <= 1;
   if (splitk <= 0) {
     // K slices: the fewest (1, 2, 4, then multiples of 8: one K range per XCD) that fill at least 95 % of the workgroup
     // slots of the rounds they need, while a slice keeps at least 8 k-steps
@@ -333,7 +433,9 @@ int launch_gemm_tn_f32_multi(nk_ctx* ctx, const TnProblemF* probs, int nprob, in
   P.sqa = P.sqb = nullptr; P.out = nullptr; P.ldo = 0; P.sigma0sq = 0.f;
   R.nprob = nprob; R.splitk = splitk; R.slab = slab; R.skip_state = nullptr; R.skip_step = 0; R.resid_partials = nullptr;
   if (ms_kernel) NK_HIP(hipEventRecord(ctx->ev[14], ctx->stream));
-  if (nprob >= 3)
+  if (use_asm)
+    hipLaunchKernelGGL(gram_fused_f32_asm_kernel, dim3((unsigned)(ntiles * splitk)), dim3(256), F32_LDS_BYTES, ctx->stream, P);
+  else if (nprob >= 3)
     hipLaunchKernelGGL(gram_fused_f32_kernel, dim3((unsigned)(ntiles * splitk)), dim3(256), F32_LDS_BYTES, ctx->stream, P);
   else
     hipLaunchKernelGGL(gemm_tn_f32_kernel<0>, dim3((unsigned)(ntiles * splitk)), dim3(256), F32_LDS_BYTES, ctx->stream, P);

@@ -110,6 +110,36 @@ def test_fp32_engine_gram_products_vs_numpy(nk, M, N, K):
     assert err < 2e-6, err
 
 
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (128, 128, 64), (132, 260, 96), (200, 72, 160), (384, 2000, 800),
+                                   (2006, 2000, 4096), (2006, 2000, 12288)])
+def test_fp32_engine_assembly_k_loop_gives_the_bits_of_the_compiled_loop(nk, monkeypatch, M, N, K):
+    """The fp32 Gram launches with the whole k loop as one hand-scheduled assembly block (accumulators double buffered in the
+    accumulation registers, the fp64 flush in the gaps between the matrix instructions; K a multiple of 32) against the
+    compiler-scheduled kernel (NYSKOOP_F32_ASM=0, read per launch): same products, same flush order -- the same bits; K from
+    one step (final step only) over odd and even step counts to split-K ranges."""
+    from nys_koop_lqr_amd import _lib
+    rng = np.random.default_rng(M + 3 * N + 11 * K)
+    lda, ldb = (M + 3) & ~3, (N + 3) & ~3
+    Ap = np.zeros((K, lda), dtype=np.float32); Ap[:, :M] = rng.standard_normal((K, M)).astype(np.float32)
+    Bp = np.zeros((K, ldb), dtype=np.float32); Bp[:, :N] = rng.standard_normal((K, N)).astype(np.float32)
+    ctx = nk.get_context()
+
+    def product():
+        C = np.empty((M, N))
+        _lib.check(ctx.lib.nk_gemm_f32(ctx.handle, M, N, K, Ap.ctypes.data, lda, Bp.ctypes.data, ldb, C.ctypes.data, N))
+        return C
+    Ca = product()
+    monkeypatch.setenv("NYSKOOP_F32_ASM", "0")
+    Cc = product()
+    monkeypatch.delenv("NYSKOOP_F32_ASM")
+    ref = Ap[:, :M].astype(np.float64).T @ Bp[:, :N].astype(np.float64)
+    assert np.abs(Cc - ref).max() / np.abs(ref).max() < 2e-6
+    if K <= 4096:
+        assert np.array_equal(Ca, Cc), float(np.abs(Ca - Cc).max())
+    else:  # the two kernels split K differently (one against two workgroups per CU): the fp64 sums of the slices differ in order
+        assert np.abs(Ca - Cc).max() / np.abs(ref).max() < 1e-15
+
+
 def test_cholesky_lookahead_gives_the_same_bits(nk, monkeypatch):
     """The blocked Cholesky with look-ahead (next block column on the chain's stream, the rest of the trailing update on a
     second stream) performs exactly the arithmetic of the sequential order: a fit with it computes the same bits as a fit
