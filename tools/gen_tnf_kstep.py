@@ -1,16 +1,22 @@
 #!/usr/bin/env python3
 """Generates nys_koop_lqr_amd/csrc/nk_tnf_kstep.inc: the whole k loop of the fp32 TN engine's Gram launches (nk_gemm_tn_f32.hip)
-as ONE inline-assembly block.  Per k-step (32 contraction rows) and wave: 64 v_mfma_f32_32x32x2_f32, and in the gaps between
-them the ds_read_b32 operand fetches of the next k-pair, the 8 LDS-DMA copies of the next step with their scalar address
-updates, the step's barrier -- and the FLUSH of the fp32 accumulators into the fp64 shadow accumulators (v_cvt_f64_f32 +
-v_add_f64 per element, 128 vector instructions per step, two per gap).
+as ONE inline-assembly block.  Per k-step (32 contraction rows) and wave: 64 v_mfma_f32_32x32x2_f32 -- four accumulator chains
+(the four 32 x 32 blocks of the wave's 64 x 64 sub-tile) alternating over 16 k-pairs -- and between them the 64 ds_read_b32
+operand fetches of the next k-pair, the 8 LDS-DMA copies of the next step with their scalar address updates, the step's
+barrier, and the FLUSH of the fp32 accumulators into the fp64 shadow accumulators (v_cvt_f64_f32 + v_add_f64 per element).
+A block is emptied where its chain pauses: the upper two behind the last two matrix instructions of a step (their chains
+restart from srcC = 0 with the first two of the next step), the lower two behind those first two.
 
-A step runs in two halves: the upper two 32 x 32 blocks of the wave's 64 x 64 sub-tile over all 16 k-pairs (two accumulator
-chains alternating), then the lower two.  While one half accumulates -- starting from srcC = 0 -- the vector ALU empties the
-accumulators of the other half into the shadows, so a flush has 32 matrix instructions of cover and never delays one.
-(Tried first: accumulators double buffered in the accumulation registers a[0:127] and emptied over a whole step.  The loop
-alone reaches 0.91 of the fp32 matrix peak, but a v_accvgpr_read_b32 beside running matrix instructions costs ~15 cycles of
-the matrix pipe each: 0.75 with the 64 reads of a step alone, 0.68 with conversions and additions.)
+What was measured on the way (C5, Gram launches, fraction of the fp32 matrix peak; the compiler-scheduled loop: 0.69):
+  * the loop without any flush: 0.91 -- the flush is what there is to lose;
+  * accumulators double buffered in the accumulation registers a[0:127], emptied over the whole next step: 0.68 -- a
+    v_accvgpr_read_b32 beside running matrix instructions costs ~15 cycles of the matrix pipe (the 64 reads of a step
+    alone: 0.75);
+  * accumulators in v[0:63], a step in two halves (upper blocks over all k-pairs, then the lower ones, each half emptied
+    while the other accumulates): 0.76 (0.87 without flush: two chains instead of four, 96 fragment reads instead of 64);
+  * this schedule: 0.76.  Wherever they stand, the 128 vector instructions of a flush cost ~3.5 cycles of the matrix pipe
+    each (64 conversions: -6 points, 64 additions: -5): instruction issue, not latency.  FLUSHMODE = none | cvt regenerates
+    the block without them (timing experiments only: wrong results).
 
 Registers: accumulators v[0:63] (block t = 2 i + j at v[16 t ...]), fragments and temporaries v[100:115] (clobbers), shadows
 v[128:255] (operands with fixed registers: inline assembly cannot name one register of a tuple operand).
@@ -23,9 +29,9 @@ PANEL_B = 32 * ROW_B       # B panel behind the A panel inside a stage
 STAGE_B = 2 * PANEL_B
 QSTEP_B = 8 * ROW_B        # LDS distance between the row pairs a wave moves (rp = wave + 4 q)
 
-SETS = [(100, 101, 102), (103, 104, 105)]   # fragment sets: (a, b0, b1)
-TMP = [108, 110, 112, 114]                  # four fp64 temporaries (register pairs)
-SH0 = 128                                   # shadows: block t at v[128 + 32 t ...]
+SETS = [((100, 101), (102, 103)), ((104, 105), (106, 107))]   # fragment sets: ((a0, a1), (b0, b1))
+TMP = [108, 110, 112, 114]                                     # four fp64 temporaries (register pairs)
+SH0 = 128                                                      # shadows: block t at v[128 + 32 t ...]
 
 
 def acc(t):
@@ -33,16 +39,16 @@ def acc(t):
 
 
 def mfma(i, j, s, first):
-    a, b0, b1 = SETS[s]
+    a, b = SETS[s]
     t = 2 * i + j
-    return f"v_mfma_f32_32x32x2_f32 {acc(t)}, v{a}, v{(b0, b1)[j]}, {'0' if first else acc(t)}"
+    return f"v_mfma_f32_32x32x2_f32 {acc(t)}, v{a[i]}, v{b[j]}, {'0' if first else acc(t)}"
 
 
-def reads(stage, kk, i, s):
-    a, b0, b1 = SETS[s]
+def reads(stage, kk, s):
+    a, b = SETS[s]
     off = stage * STAGE_B + kk * KK_B
-    return [f"ds_read_b32 v{a}, %[ard] offset:{off + 128 * i}", f"ds_read_b32 v{b0}, %[brd] offset:{off}",
-            f"ds_read_b32 v{b1}, %[brd] offset:{off + 128}"]
+    return [f"ds_read_b32 v{a[0]}, %[ard] offset:{off}", f"ds_read_b32 v{a[1]}, %[ard] offset:{off + 128}",
+            f"ds_read_b32 v{b[0]}, %[brd] offset:{off}", f"ds_read_b32 v{b[1]}, %[brd] offset:{off + 128}"]
 
 
 def dma(stage):
@@ -76,40 +82,38 @@ def flush(t):
 def main():
     lines = []
 
-    def half(st, i, last_step):
-        """16 k-pairs of block row i on LDS stage st (32 matrix instructions); empties the two blocks of the OTHER row.  The
-        fragments of its k-pair 0 are in set 0 on entry; on exit set 0 holds k-pair 0 of what follows: row 1 of this stage
-        (after i = 0), row 0 of the next stage (after i = 1; not after the last step)."""
-        other = 1 - i
-        fl = flush(2 * other) + flush(2 * other + 1)      # 64 instructions over 32 gaps
-        d = dma(1 - st) if (i == 0 and not last_step) else []
-        gaps = [fl[2 * g:2 * g + 2] for g in range(32)]
+    def step(st, last_step):
+        """one k-step on LDS stage st: four accumulator chains (the four 32 x 32 blocks of the wave's sub-tile) alternating
+        over the 16 k-pairs.  The blocks are emptied into the shadows where their chain pauses: the lower two (of the
+        PREVIOUS step) behind the first two matrix instructions -- which restart the upper two from srcC = 0 --, the upper
+        two behind the last two."""
+        d = [] if last_step else dma(1 - st)
+        gaps = [[] for _ in range(64)]
+        gaps[0] = flush(2)
+        gaps[1] = flush(3)
+        gaps[62] = flush(0)
+        gaps[63] = flush(1)
         if d:
-            per = (len(d) + 11) // 12
-            for n in range(12):       # k-pairs 2 .. 7 of the upper half
-                gaps[4 + n] = gaps[4 + n] + d[n * per:(n + 1) * per]
+            per = (len(d) + 23) // 24
+            for n in range(24):       # k-pairs 2 .. 7
+                gaps[8 + n] = gaps[8 + n] + d[n * per:(n + 1) * per]
         for kk in range(16):
             s = kk & 1
             lines.append("s_waitcnt lgkmcnt(0)")
-            if kk < 15:
-                nxt = reads(st, kk + 1, i, 1 - s)
-            elif i == 0:
-                nxt = reads(st, 0, 1, 0)
-            else:
-                nxt = [] if last_step else reads(1 - st, 0, 0, 0)
-            lines.append(mfma(i, 0, s, kk == 0))
-            if kk == 15 and i == 1 and not last_step:
-                # the step's barrier behind its 63rd matrix instruction: this wave has every fragment of the stage in registers,
-                # its DMA of the next stage was issued 50 instructions ago; then the next stage's first fragments
-                lines.extend(["s_waitcnt vmcnt(0)", "s_barrier"])
-            lines.extend(nxt)
-            lines.extend(gaps[2 * kk])
-            lines.append(mfma(i, 1, s, kk == 0))
-            lines.extend(gaps[2 * kk + 1])
-
-    def step(st, last_step):
-        half(st, 0, last_step)
-        half(st, 1, last_step)
+            nxt = reads(st, kk + 1, 1 - s) if kk < 15 else ([] if last_step else reads(1 - st, 0, 0))
+            for t, (i, j) in enumerate(((0, 0), (0, 1), (1, 0), (1, 1))):
+                lines.append(mfma(i, j, s, kk == 0))
+                if kk == 15 and not last_step:
+                    # the step's barrier behind its 61st matrix instruction (this wave has every fragment of the stage in
+                    # registers, its DMA of the next stage was issued 40 instructions ago), then the next stage's first fragments
+                    if t == 0:
+                        lines.extend(["s_waitcnt vmcnt(0)", "s_barrier"])
+                        lines.extend(nxt[0:2])
+                    elif t == 1:
+                        lines.extend(nxt[2:4])
+                elif t < len(nxt):
+                    lines.append(nxt[t])
+                lines.extend(gaps[4 * kk + t])
 
     def emit(name, body):
         nonlocal lines
@@ -122,9 +126,9 @@ def main():
 
     def whole():
         lines.extend(["s_mov_b64 s[92:93], %[rowa]", "s_mov_b64 s[94:95], %[rowb]"])
-        for r in range(32, 64):           # the first half step empties the lower blocks: make them zeros
+        for r in range(32, 64):           # the first step empties the lower blocks first: make them zeros
             lines.append(f"v_mov_b32 v{r}, 0")
-        lines.extend(reads(0, 0, 0, 0))   # k-pair 0 of block row 0, stage 0 (filled and fenced by the caller)
+        lines.extend(reads(0, 0, 0))      # k-pair 0 of stage 0 (filled and fenced by the caller)
         lines.extend(["s_cmp_eq_u32 %[cnt], 0", "s_cbranch_scc1 nk_tnf_after_%=", "nk_tnf_loop_%=:"])
         step(0, False)
         step(1, False)
@@ -136,7 +140,7 @@ def main():
         step(0, True)
         lines.append("nk_tnf_end_%=:")
         lines.extend(["s_nop 7", "s_nop 7", "s_nop 7"])   # the last matrix instructions have written their blocks
-        lines.extend(flush(2) + flush(3))              # (the upper blocks were emptied during the last lower half)
+        lines.extend(flush(2) + flush(3))              # (the upper blocks were emptied behind the last two matrix instructions)
 
     print("// GENERATED by tools/gen_tnf_kstep.py -- do not edit by hand.")
     print("// The k loop of the fp32 Gram launches: cnt (+s) trips of two steady k-steps (LDS stage 0, then 1), one more steady step on")
