@@ -347,6 +347,99 @@ __device__ __forceinline__ void tnf_gram_asm_body(const TnParamsF& P) {
 }
 __global__ void __launch_bounds__(256, 2) gram_fused_f32_asm_kernel(TnParamsF P) { tnf_gram_asm_body(P); }
 
+// The kernel-matrix launches (EPI >= 1) with the same assembly k loop, without shadows and flush (the fp32 accumulators are
+// the result): d a multiple of 32.  Same products in the same order as tnf_body<EPI>: the same bits.
+template <int EPI>
+__device__ __forceinline__ void tnf_kmat_asm_body(const TnParamsF& P) {
+  extern __shared__ __attribute__((aligned(16))) float fsmem[];
+  const TnDevF pr = P.p[0];
+  // every XCD group owns its landmark tile columns (see nk_gemm_tn.hip)
+  const int xcd = blockIdx.x & 7, ib = blockIdx.x >> 3;
+  const int cols = (pr.tiles_n - xcd + 7) >> 3;
+  if (cols <= 0) return;
+  const int tm = ib / cols;
+  const int tn = xcd + 8 * (ib - tm * cols);
+  if (tm * TBM >= pr.M) return;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int half = lane >> 5, l32 = lane & 31;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nfull = P.K / FBK;
+  const int ca = min(tm * TBM + l32 * 4, (pr.M - 1) & ~3);
+  const int cb = min(tn * TBM + l32 * 4, (pr.N - 1) & ~3);
+  const uint32_t lds0 = (uint32_t)(uintptr_t)fsmem;
+  f16v c00, c01, c10, c11;
+#pragma unroll
+  for (int v = 0; v < 16; ++v) { c00[v] = 0.f; c01[v] = 0.f; c10[v] = 0.f; c11[v] = 0.f; }
+  {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int rp = wave + 4 * q;
+      const int k = 2 * rp + half;
+      dma2_rows(pr.A + (int64_t)k * pr.lda + ca, lds0 + (uint32_t)(2 * rp * FROW) * 4u);
+      dma2_rows(pr.B + (int64_t)k * pr.ldb + cb, lds0 + (uint32_t)(FPANEL + 2 * rp * FROW) * 4u);
+    }
+    dma_wait_all_f();
+    __syncthreads();
+    const uint32_t ard = lds0 + (uint32_t)(half * FROW + l32 + wm * 64) * 4u;
+    const uint32_t brd = lds0 + (uint32_t)(FPANEL + half * FROW + l32 + wn * 64) * 4u;
+    const uint32_t voa = (uint32_t)(half * pr.lda + ca) * 4u;
+    const uint32_t vob = (uint32_t)(half * pr.ldb + cb) * 4u;
+    const uint32_t stra = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(pr.lda * 32));
+    const uint32_t strb = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(pr.ldb * 32));
+    const uint32_t dst0 = (uint32_t)__builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(wave * 2 * FROW) * 4u);
+    const int steady = nfull - 1;
+    uint32_t cnt = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(steady / 2));
+    const uint32_t flags = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(steady & 1));
+    const uint64_t ra = (uint64_t)(uintptr_t)(pr.A + (int64_t)(FBK + 2 * wave) * pr.lda);
+    const uint64_t rb = (uint64_t)(uintptr_t)(pr.B + (int64_t)(FBK + 2 * wave) * pr.ldb);
+    const uint64_t rowa = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(ra >> 32)) << 32) |
+                          (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)ra);
+    const uint64_t rowb = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(rb >> 32)) << 32) |
+                          (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)rb);
+    asm volatile(NK_TNF_KLOOP_PLAIN_ASM
+                 : "+{v[0:15]}"(c00), "+{v[16:31]}"(c01), "+{v[32:47]}"(c10), "+{v[48:63]}"(c11), [cnt] "+s"(cnt)
+                 : [ard] "v"(ard), [brd] "v"(brd), [voa] "v"(voa), [vob] "v"(vob), [rowa] "s"(rowa), [rowb] "s"(rowb),
+                   [stra] "s"(stra), [strb] "s"(strb), [dst0] "s"(dst0), [flags] "s"(flags)
+                 : NK_TNF_PLAIN_CLOBBERS);
+  }
+  // kernel-matrix epilogue (EPI = 1 RBF, 2 Matern-5/2, 3 linear) in fp32, as in tnf_body
+  float sbv[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = tn * TBM + wn * 64 + j * 32 + l32;
+    sbv[j] = (EPI != 3 && col < pr.N) ? P.sqb[col] : 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      const int row = tm * TBM + wm * 64 + i * 32 + 8 * (v >> 2) + 4 * half + (v & 3);
+      if (row >= pr.M) continue;
+      const float sav = EPI != 3 ? P.sqa[row] : 0.f;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int col = tn * TBM + wn * 64 + j * 32 + l32;
+        const float dot = i == 0 ? (j == 0 ? c00[v] : c01[v]) : (j == 0 ? c10[v] : c11[v]);
+        float val;
+        if (EPI == 3) {
+          val = dot + P.sigma0sq;
+        } else {
+          const float D = fmaxf(sav + sbv[j] - 2.f * dot, 0.f);
+          if (EPI == 1) {
+            val = expf(-0.5f * D);
+          } else {
+            const float t = sqrtf(D) * 2.2360679774997896f;
+            val = (1.f + t + t * t * (1.f / 3.f)) * expf(-t);
+          }
+        }
+        if (col < pr.N) P.out[(int64_t)row * P.ldo + col] = val;
+      }
+    }
+}
+template <int EPI>
+__global__ void __launch_bounds__(256, 2) kmat_f32_asm_kernel(TnParamsF P) { tnf_kmat_asm_body<EPI>(P); }
+
 // the fit's fused Gram launch in fp32, under its own name for the profiler
 __global__ void __launch_bounds__(256, 2) gram_fused_f32_kernel(TnParamsF P) { tnf_body<0>(P); }
 
@@ -365,6 +458,9 @@ static int tnf_attrs() {
   NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_f32_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, F32_LDS_BYTES));
   NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gram_fused_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, F32_LDS_BYTES));
   NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gram_fused_f32_asm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, F32_LDS_BYTES));
+  NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kmat_f32_asm_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, F32_LDS_BYTES));
+  NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kmat_f32_asm_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, F32_LDS_BYTES));
+  NK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kmat_f32_asm_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, F32_LDS_BYTES));
   done = true;
   return NK_OK;
 }
@@ -532,7 +628,15 @@ int launch_kmat_gram_f32(nk_ctx* ctx, int ktype, const float* At, int64_t ldat, 
   P.zeros = reinterpret_cast<const float*>(ctx->d_zeros); P.slab = nullptr;
   P.sqa = sqa; P.sqb = sqb; P.out = out; P.ldo = ldo; P.sigma0sq = (float)(sigma0 * sigma0);
   const unsigned grid = 8u * (unsigned)tmn * (unsigned)((tnn + 7) / 8);
-  if (ktype == NK_KERNEL_RBF)
+  const char* fa = getenv("NYSKOOP_F32_ASM");  // read per launch: 0 = the compiler-scheduled kernels
+  const bool use_asm = !(fa && fa[0] == '0') && d % FBK == 0 && d >= FBK;
+  if (use_asm && ktype == NK_KERNEL_RBF)
+    hipLaunchKernelGGL(kmat_f32_asm_kernel<1>, dim3(grid), dim3(256), F32_LDS_BYTES, ctx->stream, P);
+  else if (use_asm && ktype == NK_KERNEL_MATERN52)
+    hipLaunchKernelGGL(kmat_f32_asm_kernel<2>, dim3(grid), dim3(256), F32_LDS_BYTES, ctx->stream, P);
+  else if (use_asm)
+    hipLaunchKernelGGL(kmat_f32_asm_kernel<3>, dim3(grid), dim3(256), F32_LDS_BYTES, ctx->stream, P);
+  else if (ktype == NK_KERNEL_RBF)
     hipLaunchKernelGGL(gemm_tn_f32_kernel<1>, dim3(grid), dim3(256), F32_LDS_BYTES, ctx->stream, P);
   else if (ktype == NK_KERNEL_MATERN52)
     hipLaunchKernelGGL(gemm_tn_f32_kernel<2>, dim3(grid), dim3(256), F32_LDS_BYTES, ctx->stream, P);

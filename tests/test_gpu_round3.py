@@ -140,6 +140,29 @@ def test_fp32_engine_assembly_k_loop_gives_the_bits_of_the_compiled_loop(nk, mon
         assert np.abs(Ca - Cc).max() / np.abs(ref).max() < 1e-15
 
 
+def test_fp32_engine_fit_with_assembly_k_loops_gives_the_bits_of_the_compiled_loops(nk, monkeypatch):
+    """A whole fit on the fp32 engine (kernel blocks and Gram launches through the assembly k loops: d and the row count multiples
+    of 32) against the same fit with NYSKOOP_F32_ASM=0: identical operators."""
+    rng = np.random.default_rng(31)
+    n, d, p, m = 4096, 64, 3, 256
+    S = rng.standard_normal((n, d)); U = rng.standard_normal((n, p))
+    Y = np.tanh(S @ (rng.standard_normal((d, d)) * 0.9 / np.sqrt(d))) + U @ (rng.standard_normal((p, d)) * 0.1)
+    X = np.hstack([S, U])
+
+    def fit():
+        reg = nk.KoopmanNystromRegressor(p, kernel=nk.ThreeDimensionalKernel(6., 6., 6., d), gamma=1e-4, m=m)
+        reg.compute_dtype = "f32"
+        reg.nystrom_centers_output = np.ascontiguousarray(Y[:m].T)
+        reg.fit(X, Y)
+        return [np.array(a) for a in (reg.A, reg.B, reg.C)]
+    asm = fit()
+    monkeypatch.setenv("NYSKOOP_F32_ASM", "0")
+    compiled = fit()
+    monkeypatch.delenv("NYSKOOP_F32_ASM")
+    for a, b in zip(asm, compiled):
+        assert np.all(np.isfinite(a)) and np.array_equal(a, b)
+
+
 def test_cholesky_lookahead_gives_the_same_bits(nk, monkeypatch):
     """The blocked Cholesky with look-ahead (next block column on the chain's stream, the rest of the trailing update on a
     second stream) performs exactly the arithmetic of the sequential order: a fit with it computes the same bits as a fit

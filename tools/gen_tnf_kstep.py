@@ -38,7 +38,7 @@ def acc(t):
     return f"v[{16 * t}:{16 * t + 15}]"
 
 
-def mfma(i, j, s, first):
+def mfma(i, j, s, first):  # first: start the chain from srcC = 0
     a, b = SETS[s]
     t = 2 * i + j
     return f"v_mfma_f32_32x32x2_f32 {acc(t)}, v{a[i]}, v{b[j]}, {'0' if first else acc(t)}"
@@ -82,17 +82,18 @@ def flush(t):
 def main():
     lines = []
 
-    def step(st, last_step):
+    def step(st, last_step, plain=False):
         """one k-step on LDS stage st: four accumulator chains (the four 32 x 32 blocks of the wave's sub-tile) alternating
         over the 16 k-pairs.  The blocks are emptied into the shadows where their chain pauses: the lower two (of the
         PREVIOUS step) behind the first two matrix instructions -- which restart the upper two from srcC = 0 --, the upper
         two behind the last two."""
         d = [] if last_step else dma(1 - st)
         gaps = [[] for _ in range(64)]
-        gaps[0] = flush(2)
-        gaps[1] = flush(3)
-        gaps[62] = flush(0)
-        gaps[63] = flush(1)
+        if not plain:
+            gaps[0] = flush(2)
+            gaps[1] = flush(3)
+            gaps[62] = flush(0)
+            gaps[63] = flush(1)
         if d:
             per = (len(d) + 23) // 24
             for n in range(24):       # k-pairs 2 .. 7
@@ -102,7 +103,7 @@ def main():
             lines.append("s_waitcnt lgkmcnt(0)")
             nxt = reads(st, kk + 1, 1 - s) if kk < 15 else ([] if last_step else reads(1 - st, 0, 0))
             for t, (i, j) in enumerate(((0, 0), (0, 1), (1, 0), (1, 1))):
-                lines.append(mfma(i, j, s, kk == 0))
+                lines.append(mfma(i, j, s, kk == 0 and not plain))
                 if kk == 15 and not last_step:
                     # the step's barrier behind its 61st matrix instruction (this wave has every fragment of the stage in
                     # registers, its DMA of the next stage was issued 40 instructions ago), then the next stage's first fragments
@@ -124,23 +125,25 @@ def main():
             print(f'  "{ln}\\n\\t" \\')
         print('  ""')
 
-    def whole():
+    def whole(plain=False):
         lines.extend(["s_mov_b64 s[92:93], %[rowa]", "s_mov_b64 s[94:95], %[rowb]"])
-        for r in range(32, 64):           # the first step empties the lower blocks first: make them zeros
-            lines.append(f"v_mov_b32 v{r}, 0")
+        if not plain:
+            for r in range(32, 64):       # the first step empties the lower blocks first: make them zeros
+                lines.append(f"v_mov_b32 v{r}, 0")
         lines.extend(reads(0, 0, 0))      # k-pair 0 of stage 0 (filled and fenced by the caller)
         lines.extend(["s_cmp_eq_u32 %[cnt], 0", "s_cbranch_scc1 nk_tnf_after_%=", "nk_tnf_loop_%=:"])
-        step(0, False)
-        step(1, False)
+        step(0, False, plain)
+        step(1, False, plain)
         lines.extend(["s_sub_u32 %[cnt], %[cnt], 1", "s_cmp_lg_u32 %[cnt], 0", "s_cbranch_scc1 nk_tnf_loop_%=",
                       "nk_tnf_after_%=:", "s_bitcmp1_b32 %[flags], 0", "s_cbranch_scc0 nk_tnf_even_%="])
-        step(0, False)
-        step(1, True)
+        step(0, False, plain)
+        step(1, True, plain)
         lines.extend(["s_branch nk_tnf_end_%=", "nk_tnf_even_%=:"])
-        step(0, True)
+        step(0, True, plain)
         lines.append("nk_tnf_end_%=:")
         lines.extend(["s_nop 7", "s_nop 7", "s_nop 7"])   # the last matrix instructions have written their blocks
-        lines.extend(flush(2) + flush(3))              # (the upper blocks were emptied behind the last two matrix instructions)
+        if not plain:
+            lines.extend(flush(2) + flush(3))          # (the upper blocks were emptied behind the last two matrix instructions)
 
     print("// GENERATED by tools/gen_tnf_kstep.py -- do not edit by hand.")
     print("// The k loop of the fp32 Gram launches: cnt (+s) trips of two steady k-steps (LDS stage 0, then 1), one more steady step on")
@@ -151,9 +154,12 @@ def main():
     print("// dst0 (s: LDS byte address of this wave's first DMA row pair in stage 0).")
     print("// Clobbers v[0:63], v[100:115], s[92:95], m0, scc, memory.")
     emit("NK_TNF_KLOOP_ASM", whole)
-    cl = ['"memory"', '"m0"', '"scc"', '"s92"', '"s93"', '"s94"', '"s95"'] + [f'"v{r}"' for r in range(64)] + \
-         [f'"v{r}"' for r in range(100, 116)]
-    print("#define NK_TNF_CLOBBERS " + ", ".join(cl))
+    base = ['"memory"', '"m0"', '"scc"', '"s92"', '"s93"', '"s94"', '"s95"']
+    print("#define NK_TNF_CLOBBERS " + ", ".join(base + [f'"v{r}"' for r in range(64)] + [f'"v{r}"' for r in range(100, 116)]))
+    print("// The same loop without shadows and flush, for the kernel-matrix launches: the four accumulator blocks are operands")
+    print("// (c00 c01 c10 c11: +{v[0:15]} .. +{v[48:63]}, zero on entry) and are carried through all steps.")
+    emit("NK_TNF_KLOOP_PLAIN_ASM", lambda: whole(True))
+    print("#define NK_TNF_PLAIN_CLOBBERS " + ", ".join(base + [f'"v{r}"' for r in range(100, 108)]))
 
 
 if __name__ == "__main__":
