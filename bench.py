@@ -209,8 +209,8 @@ def real_cloth_grid_rate(nk, batch, groups):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--n", type=int, default=100000)
     ap.add_argument("--m", type=int, default=2000)
     ap.add_argument("--d", type=int, default=384)

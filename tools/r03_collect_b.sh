@@ -2,7 +2,7 @@
 # round-3 evidence, part B: profiled bench (kernel trace + stats), PMC passes on the fused Gram launch (one counter group per run)
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r03; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench_prof -o run -- python3 $R/bench.py --steps 5 --warmup 2 --cpu-baseline none --no-extras > $O/bench_profiled.log 2>&1; echo "profiled rc $?" >> $O/bench_profiled.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench_prof -o run -- python3 $R/bench.py --steps 10 --warmup 3 --cpu-baseline none --no-extras > $O/bench_profiled.log 2>&1; echo "profiled rc $?" >> $O/bench_profiled.log
 grep '^{"metric"' $O/bench_profiled.log > $O/bench_line_profiled.json
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_gram_1 -o run -- python3 $R/tools/gram_bench.py 100000 2000 6 384 3 > $O/pmc_gram_1.log 2>&1 && \
 rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/pmc_gram_2 -o run -- python3 $R/tools/gram_bench.py 100000 2000 6 384 3 > $O/pmc_gram_2.log 2>&1 && \
