@@ -97,40 +97,6 @@ __device__ __forceinline__ void dma_row(const double* row_base, uint32_t lane_of
 }
 __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-// exp(x) for x <= 0, the arithmetic of the device library's exp (same range reduction, same degree-11 Horner form with the same
-// coefficients, same operation order: the same bits) -- but with the coefficients as SCALAR operands of the fused multiply-adds.
-// The compiler's form keeps the accumulator in the destination (v_fmac_f64) and re-materialises every coefficient into a
-// vector register pair in front of it: 18 v_mov_b32 per value, plus 5 instructions of range checks that a non-positive
-// argument does not need (a clamp replaces them).  In the epilogue of the Gram-form kernel blocks every vector instruction
-// takes issue slots from the matrix pipe the other workgroup of the CU is using: 42 -> 19 instructions per exp.
-__device__ __forceinline__ double exp_nonpos(double x, double ca_v) {
-  x = fmax(x, -1100.0);                                      // exp underflows to 0 long before (the library: 0 below -1075)
-  const double k = __builtin_rint(x * __longlong_as_double(0x3ff71547652b82feLL));   // log2(e)
-  double r = __builtin_fma(__longlong_as_double((long long)0xbfe62e42fefa39efULL), k, x);   // -ln2, high part
-  r = __builtin_fma(__longlong_as_double((long long)0xbc7abc9e3b39803fULL), k, r);          // -ln2, low part
-  double p;
-#define NK_EXP_STEP(c) asm("v_fma_f64 %0, %1, %2, %3" : "=v"(p) : "v"(r), "v"(p), "s"(c))
-  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(p) : "v"(r), "v"(ca_v), "s"(__longlong_as_double(0x3e928af3fca7ab0cLL)));
-  NK_EXP_STEP(__longlong_as_double(0x3ec71dee623fde64LL));
-  NK_EXP_STEP(__longlong_as_double(0x3efa01997c89e6b0LL));
-  NK_EXP_STEP(__longlong_as_double(0x3f2a01a014761f6eLL));
-  NK_EXP_STEP(__longlong_as_double(0x3f56c16c1852b7b0LL));
-  NK_EXP_STEP(__longlong_as_double(0x3f81111111122322LL));
-  NK_EXP_STEP(__longlong_as_double(0x3fa55555555502a1LL));
-  NK_EXP_STEP(__longlong_as_double(0x3fc5555555555511LL));
-  NK_EXP_STEP(__longlong_as_double(0x3fe000000000000bLL));
-#undef NK_EXP_STEP
-  p = __builtin_fma(r, p, 1.0);
-  p = __builtin_fma(r, p, 1.0);
-  return ldexp(p, (int)k);
-}
-// the highest coefficient of exp_nonpos (0x3e5ade156a5dcb37) held in a vector register pair the compiler cannot re-materialise
-__device__ __forceinline__ double exp_nonpos_ca() {
-  double ca = __longlong_as_double(0x3e5ade156a5dcb37LL);
-  asm volatile("" : "+v"(ca));
-  return ca;
-}
-
 template <int EPI>
 __device__ __forceinline__ void tn_body(const TnParams& P) {
   extern __shared__ __attribute__((aligned(16))) double smem[];

@@ -22,10 +22,10 @@ template <int KTYPE>
 __device__ __forceinline__ double kmat_epilogue(double acc, double sigma0sq) {
 #pragma clang fp contract(off)  // the same operations in every kernel that inlines this (bits do not depend on the shape)
   if (KTYPE == NK_KERNEL_RBF) {
-    return exp(-0.5 * acc);
+    return exp_nonpos(-0.5 * acc);
   } else if (KTYPE == NK_KERNEL_MATERN52) {
     const double t = sqrt(acc) * 2.23606797749978969641;  // sqrt(5) * r
-    return (1.0 + t + t * t / 3.0) * exp(-t);
+    return (1.0 + t + t * t / 3.0) * exp_nonpos(-t);
   } else {
     return acc + sigma0sq;
   }

@@ -93,10 +93,10 @@ constexpr int CHAIN_KPT = 5;                // columns of G per thread (stride 3
 constexpr int CHAIN_ZU = 32 * CHAIN_KPT;    // padded length of [z ; u] in LDS (160)
 
 __device__ __forceinline__ double chain_kfun(int ktype, double acc, double sigma0sq) {
-  if (ktype == NK_KERNEL_RBF) return exp(-0.5 * acc);
+  if (ktype == NK_KERNEL_RBF) return exp_nonpos(-0.5 * acc);
   if (ktype == NK_KERNEL_MATERN52) {
     const double t = sqrt(acc) * 2.23606797749978969641;
-    return (1.0 + t + t * t / 3.0) * exp(-t);
+    return (1.0 + t + t * t / 3.0) * exp_nonpos(-t);
   }
   return acc + sigma0sq;
 }
