@@ -142,11 +142,10 @@ __device__ __forceinline__ double exp_nonpos_ca() {
 // exp(x) for x <= 0, the arithmetic of the device library's exp (same range reduction, same degree-11 Horner form with the same
 // coefficients, same operation order: the same bits) -- but with the coefficients as SCALAR operands of the fused multiply-adds.
 // The compiler's form keeps the accumulator in the destination (v_fmac_f64) and re-materialises every coefficient into a
-// vector register pair in front of it: 18 v_mov_b32 per value, plus 5 instructions of range checks that a non-positive
-// argument does not need (a clamp replaces them).  In the epilogue of the Gram-form kernel blocks every vector instruction
-// takes issue slots from the matrix pipe the other workgroup of the CU is using: 42 -> 19 instructions per exp.
+// vector register pair in front of it: 18 v_mov_b32 per value, plus an upper range check that a non-positive argument
+// does not need.  In the epilogue of the Gram-form kernel blocks every vector instruction
+// takes issue slots from the matrix pipe the other workgroup of the CU is using: 42 -> 21 instructions per exp.
 __device__ __forceinline__ double exp_nonpos(double x, double ca_v) {
-  x = fmax(x, -1100.0);                                      // exp underflows to 0 long before (the library: 0 below -1075)
   const double k = __builtin_rint(x * __longlong_as_double(0x3ff71547652b82feLL));   // log2(e)
   double r = __builtin_fma(__longlong_as_double((long long)0xbfe62e42fefa39efULL), k, x);   // -ln2, high part
   r = __builtin_fma(__longlong_as_double((long long)0xbc7abc9e3b39803fULL), k, r);          // -ln2, low part
@@ -164,7 +163,8 @@ __device__ __forceinline__ double exp_nonpos(double x, double ca_v) {
 #undef NK_EXP_STEP
   p = __builtin_fma(r, p, 1.0);
   p = __builtin_fma(r, p, 1.0);
-  return ldexp(p, (int)k);
+  // (the library's lower range check, which also keeps a NaN argument a NaN; its upper one cannot fire for x <= 0)
+  return x < -1075.0 ? 0.0 : ldexp(p, (int)k);
 }
 __device__ __forceinline__ double exp_nonpos(double x) { return exp_nonpos(x, exp_nonpos_ca()); }
 

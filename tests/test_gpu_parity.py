@@ -71,6 +71,12 @@ def test_kernel_matrix_golden_and_properties(nk, golden):
     with pytest.raises(ValueError):  # sklearn _check_length_scale
         nk.KernelWrapper([1.0, 2.0, 3.0]).kernel(A, B)
     assert nk.KernelWrapper([1.0] * 7).kernel(A[:0], B).shape == (0, 13)  # empty input
+    # special values go through the kernel functions as through the library's exp: coincident points 1, a point 1e9 lengthscales away 0
+    # (underflow, no NaN from the range reduction), a NaN coordinate NaN
+    S = np.array([[0.0, 0.0], [1e9, 0.0], [np.nan, 0.0]])
+    for kern in (nk.KernelWrapper([1.0, 1.0]), nk.ThreeDimensionalKernel(1.0, 1.0, 1.0, 2)):
+        Ks = kern.kernel(S, np.array([[0.0, 0.0], [1.0, 1.0]]))
+        assert Ks[0, 0] == 1.0 and np.all(Ks[1] == 0.0) and np.all(np.isnan(Ks[2]))
 
 
 # ---------------------------------------------------------------------------------------------------------------
